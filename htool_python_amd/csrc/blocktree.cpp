@@ -1,0 +1,136 @@
+// blocktree.cpp -- block cluster tree, produced directly as two flat work queues.
+//
+// Replaces the recursive block-tree construction inside htool::HMatrixTreeBuilder::build
+// (entered from src/htool/hmatrix/hmatrix_tree_builder.hpp:36; parameters :23-43).  lib/htool is
+// not vendored; the recursion follows SURVEY.md Appendix A.3:
+//   admissible(t,s) := 2 min(r_t, r_s) < eta * max(0, |c_t - c_s| - r_t - r_s)
+//   admissible and deep enough -> low-rank queue; both leaves -> dense queue; otherwise split the
+//   larger side (both when equal).
+// No pointer tree is kept: a leaf is the record (t_off, m, s_off, n, rank) of
+// src/htool/matplotlib/hmatrix.hpp:18-22.
+//
+// Symmetric storage ('S'/'H' with UPLO): this engine stores BOTH triangles (the product is then a
+// plain sweep over row tiles with no transposed pass); results are identical to the reference's up
+// to the compression tolerance, memory is not halved.  See DESIGN.md "symmetry".
+#include <cmath>
+
+#include "hmatrix.hpp"
+
+namespace hm {
+
+namespace {
+
+struct Ctx {
+    const ClusterTree &T, &S;
+    const BuildParams &P;
+    std::vector<BlockRec> &adm, &dns;
+};
+
+BlockRec make_block(const Ctx &c, int t, int s) {
+    BlockRec b;
+    b.t_node = t;
+    b.s_node = s;
+    b.t_off = c.T.offset[t];
+    b.m = c.T.size[t];
+    b.s_off = c.S.offset[s];
+    b.n = c.S.size[s];
+    b.rank = -1;
+    b.cap = 0;
+    b.batch = -1;
+    b.tmp_u = b.tmp_v = 0;
+    b.ucol = b.vcol = 0;
+    b.tpos = 0;
+    b.v_obase = 0;
+    b.v_ostride = 0;
+    b.status = 0;
+    return b;
+}
+
+bool admissible(const Ctx &c, int t, int s) {
+    double dx = c.T.cx[t] - c.S.cx[s], dy = c.T.cy[t] - c.S.cy[s], dz = c.T.cz[t] - c.S.cz[s];
+    double dist = std::sqrt(dx * dx + dy * dy + dz * dz) - c.T.radius[t] - c.S.radius[s];
+    return 2 * std::min(c.T.radius[t], c.S.radius[s]) < c.P.eta * std::max(0.0, dist);
+}
+
+void visit(const Ctx &c, int t, int s);
+
+void split(const Ctx &c, int t, int s) {
+    const bool lt = c.T.is_leaf(t), ls = c.S.is_leaf(s);
+    if (lt && ls) {
+        c.dns.push_back(make_block(c, t, s));
+        return;
+    }
+    if (ls || (!lt && c.T.size[t] > c.S.size[s])) {
+        for (int a = 0; a < c.T.n_child[t]; a++) visit(c, c.T.first_child[t] + a, s);
+    } else if (lt || c.S.size[s] > c.T.size[t]) {
+        for (int b = 0; b < c.S.n_child[s]; b++) visit(c, t, c.S.first_child[s] + b);
+    } else {
+        for (int a = 0; a < c.T.n_child[t]; a++)
+            for (int b = 0; b < c.S.n_child[s]; b++) visit(c, c.T.first_child[t] + a, c.S.first_child[s] + b);
+    }
+}
+
+void visit(const Ctx &c, int t, int s) {
+    if (c.T.size[t] == 0 || c.S.size[s] == 0) return;
+    if (admissible(c, t, s) && c.T.depth[t] >= c.P.min_target_depth && c.S.depth[s] >= c.P.min_source_depth) {
+        c.adm.push_back(make_block(c, t, s));
+        return;
+    }
+    split(c, t, s);
+}
+
+} // namespace
+
+void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int /*sym_partition*/,
+                      std::vector<BlockRec> &adm, std::vector<BlockRec> &dns) {
+    Ctx c{T, S, P, adm, dns};
+    visit(c, t_root, 0);
+}
+
+void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, const BlockRec &b,
+                        std::vector<BlockRec> &adm, std::vector<BlockRec> &dns) {
+    Ctx c{T, S, P, adm, dns};
+    split(c, b.t_node, b.s_node);
+}
+
+TileSet make_tiles(const ClusterTree &T, int root_node, int tile_max) {
+    TileSet ts;
+    const int nn = T.node_count();
+    ts.node_tile_begin.assign(nn, 0);
+    ts.node_tile_end.assign(nn, 0);
+    // depth-first walk in offset order; leaves are cut into ceil(size/tile_max) nearly equal pieces
+    std::vector<int> stack{root_node};
+    std::vector<int> order; // post-order bookkeeping
+    std::vector<std::pair<int, int>> st;
+    st.push_back(std::make_pair(root_node, 0));
+    while (!st.empty()) {
+        int id = st.back().first, phase = st.back().second;
+        if (phase == 0) {
+            ts.node_tile_begin[id] = ts.count();
+            st.back().second = 1;
+            if (T.is_leaf(id)) {
+                int sz = T.size[id], np = (sz + tile_max - 1) / tile_max;
+                int o = T.offset[id];
+                for (int p = 0; p < np; p++) {
+                    int len = sz / np + (p < sz % np ? 1 : 0);
+                    ts.off.push_back(o);
+                    ts.size.push_back(len);
+                    ts.leaf_of_tile.push_back(id);
+                    o += len;
+                }
+            } else {
+                for (int c = T.n_child[id] - 1; c >= 0; c--) st.push_back(std::make_pair(T.first_child[id] + c, 0));
+            }
+        } else {
+            ts.node_tile_end[id] = ts.count();
+            st.pop_back();
+        }
+    }
+    return ts;
+}
+
+HMatrix::~HMatrix() {
+    if (dev) device_free(dev);
+}
+
+} // namespace hm

@@ -1,0 +1,175 @@
+// build_host.cpp -- leaf filling for CALLBACK generators (user code in the host language).
+//
+// A callback generator (Python VirtualGenerator.build_submatrix, reference trampoline
+// src/htool/hmatrix/interfaces/virtual_generator.hpp:16-25) can only be evaluated on the host, on
+// the calling thread (the reference builds with HTOOL_WITH_PYTHON_INTERFACE for the same reason,
+// CMakeLists.txt:97).  This file therefore runs, on the host: the partially pivoted ACA that drives
+// the callback row by row / column by column, or the user's compressor
+// (virtual_low_rank_generator.hpp:25-45), and the dense fill (virtual_generator.hpp or
+// virtual_dense_blocks_generator.hpp:21-35).  The resulting panels go to a host arena laid out like
+// the device's temporary arena and are packed and multiplied on the GPU exactly like device-built
+// ones.  Native generators never come here (device_build_native).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "hmatrix.hpp"
+
+namespace hm {
+
+namespace {
+
+inline double abs2(double x) { return x * x; }
+inline double abs2(const cplx &x) { return std::norm(x); }
+inline double cj(double x) { return x; }
+inline cplx cj(const cplx &x) { return std::conj(x); }
+inline double re(double x) { return x; }
+inline double re(const cplx &x) { return x.real(); }
+
+// returns rank (>=0) or -1 when the block is not worth storing in low-rank form
+template <typename T>
+int host_aca(const Generator &g, int M, int N, const int *rows, const int *cols, double eps, int reqrank, std::vector<T> &U, std::vector<T> &V) {
+    U.clear();
+    V.clear();
+    std::vector<char> urow(M, 0), ucol(N, 0);
+    std::vector<T> r(N), c(M);
+    int k = 0, I = 0;
+    double frob2 = 0;
+    const int kmax = std::min(M, N);
+    while (k < kmax) {
+        if (reqrank >= 0 && k >= reqrank) break;
+        g.fn(g.ctx, 1, N, rows + I, cols, r.data());
+        for (int l = 0; l < k; l++) {
+            T u = U[(size_t)l * M + I];
+            const T *v = &V[(size_t)l * N];
+            for (int j = 0; j < N; j++) r[j] -= u * v[j];
+        }
+        urow[I] = 1;
+        int J = -1;
+        double best = -1;
+        for (int j = 0; j < N; j++)
+            if (!ucol[j]) {
+                double a = abs2(r[j]);
+                if (a > best) best = a, J = j;
+            }
+        if (J < 0) break;
+        if (std::sqrt(best) <= 1e-15) {
+            int nI = -1;
+            for (int i = 0; i < M; i++)
+                if (!urow[i]) { nI = i; break; }
+            if (nI < 0) break;
+            I = nI;
+            continue;
+        }
+        T piv = r[J];
+        g.fn(g.ctx, M, 1, rows, cols + J, c.data());
+        for (int l = 0; l < k; l++) {
+            T v = V[(size_t)l * N + J];
+            const T *u = &U[(size_t)l * M];
+            for (int i = 0; i < M; i++) c[i] -= v * u[i];
+        }
+        T inv = T(1) / piv;
+        for (int i = 0; i < M; i++) c[i] *= inv;
+        ucol[J] = 1;
+        double cn2 = 0, rn2 = 0;
+        for (int i = 0; i < M; i++) cn2 += abs2(c[i]);
+        for (int j = 0; j < N; j++) rn2 += abs2(r[j]);
+        double cross = 0;
+        for (int l = 0; l < k; l++) {
+            T a = 0, b = 0;
+            const T *u = &U[(size_t)l * M], *v = &V[(size_t)l * N];
+            for (int i = 0; i < M; i++) a += cj(u[i]) * c[i];
+            for (int j = 0; j < N; j++) b += cj(v[j]) * r[j];
+            cross += re(a * b);
+        }
+        frob2 += 2 * cross + cn2 * rn2;
+        U.insert(U.end(), c.begin(), c.end());
+        V.insert(V.end(), r.begin(), r.end());
+        k++;
+        if ((int64_t)k * (M + N) > (int64_t)M * N) return -1;
+        if (reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0))) break;
+        int nI = -1;
+        double bc = -1;
+        for (int i = 0; i < M; i++)
+            if (!urow[i]) {
+                double a = abs2(c[i]);
+                if (a > bc) bc = a, nI = i;
+            }
+        if (nI < 0) break;
+        I = nI;
+    }
+    return k;
+}
+
+} // namespace
+
+template <typename T>
+void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
+    const ClusterTree &Tt = *H.tc, &Ss = *H.sc;
+    const BuildParams &P = H.params;
+    std::vector<BlockRec> adm, dns, done;
+    build_block_tree(Tt, Ss, P, H.t_root, -1, adm, dns);
+    arena.clear();
+    std::vector<T> U, V;
+    // low-rank queue; failures are re-split and appended to the queues
+    for (size_t q = 0; q < adm.size(); q++) {
+        BlockRec b = adm[q];
+        const int *rows = &Tt.perm[b.t_off], *cols = &Ss.perm[b.s_off];
+        int rank = -1;
+        if (P.compress) {
+            const void *pu = nullptr, *pv = nullptr;
+            int r = 0;
+            int ok = P.compress(P.compress_ctx, b.m, b.n, rows, cols, P.epsilon, &pu, &pv, &r);
+            if (ok) {
+                rank = r;
+                U.assign((const T *)pu, (const T *)pu + (size_t)r * b.m);
+                V.resize((size_t)r * b.n);
+                const T *vv = (const T *)pv; // r x n column-major -> step-major [k][j]
+                for (int j = 0; j < b.n; j++)
+                    for (int k = 0; k < r; k++) V[(size_t)k * b.n + j] = vv[(size_t)j * r + k];
+            }
+        } else {
+            rank = host_aca<T>(g, b.m, b.n, rows, cols, P.epsilon, P.reqrank, U, V);
+        }
+        if (rank < 0) {
+            split_failed_block(Tt, Ss, P, b, adm, dns);
+            continue;
+        }
+        b.rank = rank;
+        b.cap = rank;
+        b.tmp_u = (int64_t)arena.size();
+        arena.insert(arena.end(), U.begin(), U.begin() + (size_t)rank * b.m);
+        b.tmp_v = (int64_t)arena.size();
+        arena.insert(arena.end(), V.begin(), V.begin() + (size_t)rank * b.n);
+        done.push_back(b);
+    }
+    // dense queue
+    size_t base = arena.size(), total = 0;
+    for (BlockRec &b : dns) {
+        b.rank = -1;
+        b.tmp_u = (int64_t)(base + total);
+        total += (size_t)b.m * b.n;
+    }
+    arena.resize(base + total);
+    if (P.dense_blocks && !dns.empty()) {
+        std::vector<int> M, N, ro, co;
+        std::vector<void *> ptrs;
+        for (BlockRec &b : dns) {
+            M.push_back(b.m);
+            N.push_back(b.n);
+            ro.push_back(b.t_off);
+            co.push_back(b.s_off);
+            ptrs.push_back(&arena[b.tmp_u]);
+        }
+        P.dense_blocks(P.dense_blocks_ctx, (int)dns.size(), M.data(), N.data(), ro.data(), co.data(), ptrs.data());
+    } else {
+        for (BlockRec &b : dns) g.fn(g.ctx, b.m, b.n, &Tt.perm[b.t_off], &Ss.perm[b.s_off], &arena[b.tmp_u]);
+    }
+    H.blocks = done;
+    H.blocks.insert(H.blocks.end(), dns.begin(), dns.end());
+}
+
+template void host_fill_blocks<double>(const Generator &, HMatrix &, std::vector<double> &);
+template void host_fill_blocks<cplx>(const Generator &, HMatrix &, std::vector<cplx> &);
+
+} // namespace hm

@@ -1,0 +1,431 @@
+// capi.cpp -- extern "C" surface declared in include/htool_mi355x.h
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <sstream>
+
+#include "../../include/htool_mi355x.h"
+#include "hmatrix.hpp"
+
+using namespace hm;
+
+struct htool_cluster {}; // never instantiated: handles are hm::ClusterHandle
+struct htool_generator {
+    Generator g;
+};
+struct htool_hmatrix {
+    HMatrix H;
+    ClusterHandle *tch = nullptr, *sch = nullptr;
+};
+struct htool_distributed {
+    htool_hmatrix *hmat = nullptr;
+    htool_comm comm;
+    const ClusterTree *tc = nullptr, *sc = nullptr;
+    std::vector<int64_t> counts, displs; // rows per rank / first row per rank (cluster numbering)
+};
+
+static thread_local std::string g_err;
+
+#define API_BEGIN try {
+#define API_END                                              \
+    }                                                        \
+    catch (const std::exception &e) {                        \
+        g_err = e.what();                                    \
+        return 1;                                            \
+    }                                                        \
+    catch (...) {                                            \
+        g_err = "unknown error";                             \
+        return 1;                                            \
+    }                                                        \
+    return 0;
+
+static inline const ClusterHandle *CH(const htool_cluster *c) { return reinterpret_cast<const ClusterHandle *>(c); }
+
+extern "C" {
+
+const char *htool_last_error(void) { return g_err.c_str(); }
+int htool_device_count(void) { return device_count(); }
+int htool_set_device(int device) {
+    API_BEGIN
+    device_select(device);
+    API_END
+}
+const char *htool_device_name(void) {
+    static thread_local std::string s;
+    s = device_name();
+    return s.c_str();
+}
+
+void htool_set_log_sink(htool_log_sink sink) { set_log_sink(sink); }
+void htool_test_logger(void) {
+    log_message(LOG_CRITICAL, "Critical message");
+    log_message(LOG_ERROR, "Error message");
+    log_message(LOG_WARNING, "Warning message");
+    log_message(LOG_DEBUG, "Debug message");
+    log_message(LOG_INFO, "Info message");
+}
+
+// ---- cluster ---------------------------------------------------------------------------------
+int htool_cluster_create(const double *coordinates, int n_points, int dim, const double *radii, const double *weights, int number_of_children,
+                         int size_of_partition, const int *partition, int partition_is_local, int maximal_leaf_size, int strategy, htool_cluster **out) {
+    API_BEGIN
+    ClusterBuildArgs a{coordinates, n_points, dim, radii, weights, number_of_children, size_of_partition, partition, partition_is_local != 0, maximal_leaf_size, strategy};
+    ClusterTree *T = build_cluster_tree(a);
+    *out = reinterpret_cast<htool_cluster *>(T->handle(0));
+    API_END
+}
+void htool_cluster_destroy(htool_cluster *root) {
+    if (root) delete CH(root)->tree;
+}
+int htool_cluster_size(const htool_cluster *c) { return CH(c)->tree->size[CH(c)->node]; }
+int htool_cluster_offset(const htool_cluster *c) { return CH(c)->tree->offset[CH(c)->node]; }
+int htool_cluster_maximal_leaf_size(const htool_cluster *c) { return CH(c)->tree->max_leaf; }
+const int *htool_cluster_permutation(const htool_cluster *c, int *n) {
+    if (n) *n = CH(c)->tree->n_points;
+    return CH(c)->tree->perm.data();
+}
+const htool_cluster *htool_cluster_on_partition(const htool_cluster *c, int p) {
+    ClusterTree *T = CH(c)->tree;
+    if (p < 0 || p >= (int)T->part_nodes.size()) {
+        g_err = "partition index out of range";
+        return nullptr;
+    }
+    return reinterpret_cast<const htool_cluster *>(T->handle(T->part_nodes[p]));
+}
+int htool_cluster_dimension(const htool_cluster *c) { return CH(c)->tree->dim; }
+int htool_cluster_node_count(const htool_cluster *c) { return CH(c)->tree->node_count(); }
+int htool_cluster_node_id(const htool_cluster *c) { return CH(c)->node; }
+void htool_cluster_nodes(const htool_cluster *c, int *ints7, double *doubles4) {
+    const ClusterTree &T = *CH(c)->tree;
+    for (int i = 0; i < T.node_count(); i++) {
+        int *p = ints7 + 7 * i;
+        p[0] = T.offset[i]; p[1] = T.size[i]; p[2] = T.depth[i]; p[3] = T.parent[i]; p[4] = T.first_child[i]; p[5] = T.n_child[i]; p[6] = T.partition[i];
+        double *q = doubles4 + 4 * i;
+        q[0] = T.cx[i]; q[1] = T.cy[i]; q[2] = T.cz[i]; q[3] = T.radius[i];
+    }
+}
+
+// ---- generators --------------------------------------------------------------------------------
+int htool_generator_create_callback(int is_complex, htool_copy_submatrix_fn fn, void *ctx, htool_generator **out) {
+    API_BEGIN
+    HM_CHECK(fn != nullptr, "generator callback is null");
+    htool_generator *g = new htool_generator;
+    g->g.is_complex = is_complex != 0;
+    g->g.native = false;
+    g->g.fn = fn;
+    g->g.ctx = ctx;
+    *out = g;
+    API_END
+}
+int htool_generator_create_native(int kind, int dim, const double *target_points, int n_target, const double *source_points, int n_source,
+                                  double param, htool_generator **out) {
+    API_BEGIN
+    HM_CHECK(kind >= 0 && kind <= 2, "unknown native kernel kind");
+    HM_CHECK(dim >= 1 && dim <= 3, "native generator: dimension must be 1, 2 or 3");
+    htool_generator *g = new htool_generator;
+    g->g.native = true;
+    g->g.kind = kind;
+    g->g.dim = dim;
+    g->g.param = param;
+    g->g.is_complex = kind == HTOOL_KERNEL_HELMHOLTZ;
+    g->g.n_target = n_target;
+    g->g.n_source = n_source;
+    g->g.tpts.assign(target_points, target_points + (size_t)n_target * dim);
+    g->g.spts.assign(source_points, source_points + (size_t)n_source * dim);
+    *out = g;
+    API_END
+}
+int htool_generator_is_complex(const htool_generator *g) { return g->g.is_complex ? 1 : 0; }
+void htool_generator_destroy(htool_generator *g) { delete g; }
+
+void htool_build_params_default(htool_build_params *p) {
+    std::memset(p, 0, sizeof(*p));
+    p->epsilon = 1e-3;
+    p->eta = 10;
+    p->symmetry = 'N';
+    p->uplo = 'N';
+    p->reqrank = -1;
+    p->block_tree_consistency = 1;
+}
+
+// ---- H-matrix ----------------------------------------------------------------------------------
+static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
+                                    const htool_build_params *params, int target_partition) {
+    HM_CHECK(g && target_root && source_root && params, "htool_hmatrix_build: null argument");
+    ClusterTree *T = CH(target_root)->tree, *S = CH(source_root)->tree;
+    HM_CHECK(params->symmetry == 'N' || params->symmetry == 'S' || params->symmetry == 'H', "symmetry must be 'N', 'S' or 'H'");
+    HM_CHECK(params->uplo == 'N' || params->uplo == 'L' || params->uplo == 'U', "UPLO must be 'N', 'L' or 'U'");
+    if (g->g.native) {
+        HM_CHECK(g->g.n_target == T->n_points && g->g.n_source == S->n_points, "native generator: point counts do not match the clusters");
+        HM_CHECK(g->g.dim == T->dim && g->g.dim == S->dim, "native generator: dimension does not match the clusters");
+    }
+    HM_CHECK(device_count() > 0, "no HIP device available: libhtool_mi355x has no CPU fallback (HIP path required)");
+    std::unique_ptr<htool_hmatrix> h(new htool_hmatrix);
+    HMatrix &H = h->H;
+    H.tc = T;
+    H.sc = S;
+    H.is_complex = g->g.is_complex;
+    H.params.epsilon = params->epsilon;
+    H.params.eta = params->eta;
+    H.params.symmetry = params->symmetry;
+    H.params.uplo = params->uplo;
+    H.params.reqrank = params->reqrank;
+    H.params.min_target_depth = params->minimal_target_depth;
+    H.params.min_source_depth = params->minimal_source_depth;
+    H.params.block_tree_consistency = params->block_tree_consistency;
+    H.params.compress = params->compress;
+    H.params.compress_ctx = params->compress_ctx;
+    H.params.dense_blocks = params->dense_blocks;
+    H.params.dense_blocks_ctx = params->dense_blocks_ctx;
+    if (target_partition >= 0) {
+        HM_CHECK(target_partition < (int)T->part_nodes.size(), "target_partition_number out of range");
+        H.t_root = T->part_nodes[target_partition];
+    } else {
+        H.t_root = 0;
+    }
+    H.row_off = T->offset[H.t_root];
+    H.row_size = T->size[H.t_root];
+    H.tile_max = H.is_complex ? 64 : 128;
+    H.rtiles = make_tiles(*T, H.t_root, H.tile_max);
+    H.ctiles = make_tiles(*S, 0, H.tile_max);
+    h->tch = T->handle(H.t_root);
+    h->sch = S->handle(0);
+    double t0 = wall_seconds();
+    if (g->g.native) {
+        device_build_native(H, g->g);
+    } else if (H.is_complex) {
+        std::vector<cplx> arena;
+        host_fill_blocks<cplx>(g->g, H, arena);
+        device_build_from_host(H, arena.data(), (int64_t)arena.size());
+    } else {
+        std::vector<double> arena;
+        host_fill_blocks<double>(g->g, H, arena);
+        device_build_from_host(H, arena.data(), (int64_t)arena.size());
+    }
+    H.build_seconds = wall_seconds() - t0;
+    log_message(LOG_INFO, strprintf("H-matrix built: %zu leaves, %.3f s", H.blocks.size(), H.build_seconds));
+    return h.release();
+}
+
+int htool_hmatrix_build(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
+                        int target_partition_number, int /*partition_number_for_symmetry*/, htool_hmatrix **out) {
+    API_BEGIN
+    *out = build_hmatrix(g, target_root, source_root, params, target_partition_number);
+    API_END
+}
+void htool_hmatrix_destroy(htool_hmatrix *h) { delete h; }
+int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
+    API_BEGIN
+    std::unique_ptr<htool_hmatrix> c(new htool_hmatrix);
+    const HMatrix &s = h->H;
+    HMatrix &d = c->H;
+    d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
+    d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.blocks = s.blocks; d.r_elems = s.r_elems;
+    d.build_seconds = s.build_seconds; d.n_batches = s.n_batches;
+    c->tch = h->tch; c->sch = h->sch;
+    device_clone(s, d);
+    *out = c.release();
+    API_END
+}
+int htool_hmatrix_is_complex(const htool_hmatrix *h) { return h->H.is_complex ? 1 : 0; }
+int htool_hmatrix_nb_rows(const htool_hmatrix *h) { return h->H.row_size; }
+int htool_hmatrix_nb_cols(const htool_hmatrix *h) { return h->H.sc->n_points; }
+const htool_cluster *htool_hmatrix_target_cluster(const htool_hmatrix *h) { return reinterpret_cast<const htool_cluster *>(h->tch); }
+const htool_cluster *htool_hmatrix_source_cluster(const htool_hmatrix *h) { return reinterpret_cast<const htool_cluster *>(h->sch); }
+
+} // extern "C"
+
+template <typename T>
+static void axpby(size_t n, T alpha, const T *t, T beta, T *y) {
+    for (size_t i = 0; i < n; i++) y[i] = alpha * t[i] + (beta == T(0) ? T(0) : beta * y[i]);
+}
+
+static void matvec_scaled(const HMatrix &H, const void *alpha, const void *x, const void *beta, void *y) {
+    const size_t n = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+    if (H.is_complex) {
+        cplx a = alpha ? *(const cplx *)alpha : cplx(1), b = beta ? *(const cplx *)beta : cplx(0);
+        if (a == cplx(1) && b == cplx(0)) { device_matvec_host(H, x, y); return; }
+        std::vector<cplx> t(n);
+        device_matvec_host(H, x, t.data());
+        axpby<cplx>(n, a, t.data(), b, (cplx *)y);
+    } else {
+        double a = alpha ? *(const double *)alpha : 1.0, b = beta ? *(const double *)beta : 0.0;
+        if (a == 1.0 && b == 0.0) { device_matvec_host(H, x, y); return; }
+        std::vector<double> t(n);
+        device_matvec_host(H, x, t.data());
+        axpby<double>(n, a, t.data(), b, (double *)y);
+    }
+}
+
+extern "C" {
+
+int htool_hmatrix_matvec(const htool_hmatrix *h, char trans, const void *alpha, const void *x, const void *beta, void *y) {
+    API_BEGIN
+    HM_CHECK(trans == 'N', "H-matrix product: only trans='N' is implemented on the HIP path");
+    matvec_scaled(h->H, alpha, x, beta, y);
+    API_END
+}
+int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, const void *X, int mu, const void *beta, void *Y) {
+    API_BEGIN
+    HM_CHECK(trans == 'N', "H-matrix product: only trans='N' is implemented on the HIP path");
+    const HMatrix &H = h->H;
+    const size_t es = H.is_complex ? 16 : 8;
+    const size_t nin = (size_t)H.sc->n_points, nout = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+    for (int c = 0; c < mu; c++) matvec_scaled(H, alpha, (const char *)X + c * nin * es, beta, (char *)Y + c * nout * es);
+    API_END
+}
+int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream) {
+    API_BEGIN
+    HM_CHECK(numbering == 0 || numbering == 1, "numbering must be 0 (user) or 1 (cluster)");
+    HM_CHECK(numbering == 1 || h->H.t_root == 0, "user numbering needs an H-matrix built on the whole target cluster");
+    device_matvec_device(h->H, x_dev, y_dev, numbering, stream);
+    API_END
+}
+
+int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering) {
+    API_BEGIN
+    // dense(H) = H * I, one product per column (test-sized operators only: O(N^2) output)
+    const HMatrix &H = h->H;
+    const size_t es = H.is_complex ? 16 : 8;
+    const int ns = H.sc->n_points;
+    const size_t nr = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+    std::vector<char> e((size_t)ns * es, 0), col(nr * es);
+    const double one = 1.0, zero = 0.0;
+    for (int j = 0; j < ns; j++) {
+        // unit vector in user numbering that selects cluster column j (or user column j)
+        int uj = user_numbering ? j : H.sc->perm[j];
+        std::memcpy(&e[(size_t)uj * es], &one, sizeof(double));
+        device_matvec_host(H, e.data(), col.data());
+        std::memcpy(&e[(size_t)uj * es], &zero, sizeof(double));
+        char *dst = (char *)out + (size_t)j * nr * es;
+        if (user_numbering || H.t_root != 0) {
+            std::memcpy(dst, col.data(), nr * es);
+        } else {
+            for (size_t i = 0; i < nr; i++) std::memcpy(dst + i * es, &col[(size_t)H.tc->perm[i] * es], es);
+        }
+    }
+    API_END
+}
+
+int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.blocks.size(); }
+void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5) {
+    for (size_t i = 0; i < h->H.blocks.size(); i++) {
+        const BlockRec &b = h->H.blocks[i];
+        int *p = out5 + 5 * i;
+        p[0] = b.t_off; p[1] = b.m; p[2] = b.s_off; p[3] = b.n; p[4] = b.rank;
+    }
+}
+int htool_hmatrix_leaf_panels(const htool_hmatrix *h, int64_t leaf, void *A, void *B) {
+    API_BEGIN
+    device_leaf_panels(h->H, leaf, A, B);
+    API_END
+}
+
+void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8) {
+    const HMatrix &H = h->H;
+    int64_t dense = 0, lr = 0, nd = 0, nl = 0, sr = 0, maxr = 0;
+    for (const BlockRec &b : H.blocks) {
+        if (b.rank < 0) { dense += (int64_t)b.m * b.n; nd++; }
+        else { lr += (int64_t)b.rank * (b.m + b.n); nl++; sr += b.rank; maxr = std::max<int64_t>(maxr, b.rank); }
+    }
+    out8[0] = dense; out8[1] = lr; out8[2] = nd; out8[3] = nl; out8[4] = sr;
+    out8[5] = device_resident_bytes(H);
+    out8[6] = (int64_t)(H.build_seconds * 1e6);
+    out8[7] = maxr;
+}
+double htool_hmatrix_last_product_us(const htool_hmatrix *h) { return device_last_product_us(h->H); }
+
+int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap) {
+    const HMatrix &H = h->H;
+    std::ostringstream o;
+    if (which == 0) {
+        o << "Eta=" << H.params.eta << "\nEpsilon=" << H.params.epsilon << "\nTarget_size=" << H.row_size << "\nSource_size=" << H.sc->n_points
+          << "\nDimension=" << H.tc->dim << "\nTarget_minclustersize=" << H.tc->max_leaf << "\nSource_minclustersize=" << H.sc->max_leaf
+          << "\nSymmetry=" << H.params.symmetry << "\nUPLO=" << H.params.uplo << "\nBackend=HIP gfx950\nTile_size=" << H.tile_max << "\n";
+    } else {
+        int64_t st[8];
+        htool_hmatrix_stats(h, st);
+        int64_t dmin = -1, dmax = 0, lmin = -1, lmax = 0, rmin = -1;
+        double rmean = 0;
+        for (const BlockRec &b : H.blocks) {
+            int64_t sz = (int64_t)b.m * b.n;
+            if (b.rank < 0) { dmin = dmin < 0 ? sz : std::min(dmin, sz); dmax = std::max(dmax, sz); }
+            else { lmin = lmin < 0 ? sz : std::min(lmin, sz); lmax = std::max(lmax, sz); rmin = rmin < 0 ? b.rank : std::min<int64_t>(rmin, b.rank); rmean += b.rank; }
+        }
+        if (st[3]) rmean /= (double)st[3];
+        double full = (double)H.row_size * (double)H.sc->n_points;
+        double cr = full > 0 ? (double)(st[0] + st[1]) / full : 0;
+        o << "Number_of_dense_blocks=" << st[2] << "\nNumber_of_low_rank_blocks=" << st[3] << "\nDense_block_size_max=" << dmax << "\nDense_block_size_min=" << std::max<int64_t>(dmin, 0)
+          << "\nLow_rank_block_size_max=" << lmax << "\nLow_rank_block_size_min=" << std::max<int64_t>(lmin, 0) << "\nRank_max=" << st[7] << "\nRank_min=" << std::max<int64_t>(rmin, 0)
+          << "\nRank_mean=" << rmean << "\nCompression_ratio=" << (cr > 0 ? 1.0 / cr : 0) << "\nSpace_saving=" << 1 - cr << "\nHBM_bytes=" << st[5]
+          << "\nBuild_seconds=" << H.build_seconds << "\n";
+    }
+    std::string s = o.str();
+    if (buf && cap > 0) {
+        int n = std::min<int>((int)s.size(), cap - 1);
+        std::memcpy(buf, s.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return (int)s.size() + 1;
+}
+
+// ---- distributed operator ----------------------------------------------------------------------
+int htool_distributed_create_default(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
+                                     const htool_build_params *params, const htool_comm *comm, htool_distributed **out) {
+    API_BEGIN
+    HM_CHECK(comm != nullptr, "communicator is null");
+    ClusterTree *T = CH(target_root)->tree;
+    HM_CHECK((int)T->part_nodes.size() == comm->size, strprintf("target cluster has %zu partitions but the communicator has %d ranks", T->part_nodes.size(), comm->size));
+    std::unique_ptr<htool_distributed> d(new htool_distributed);
+    d->comm = *comm;
+    d->tc = T;
+    d->sc = CH(source_root)->tree;
+    for (int p = 0; p < comm->size; p++) {
+        d->counts.push_back(T->size[T->part_nodes[p]]);
+        d->displs.push_back(T->offset[T->part_nodes[p]]);
+    }
+    d->hmat = build_hmatrix(g, target_root, source_root, params, comm->size == 1 && T->part_nodes[0] == 0 ? -1 : comm->rank);
+    *out = d.release();
+    API_END
+}
+void htool_distributed_destroy(htool_distributed *d) {
+    if (d) { delete d->hmat; delete d; }
+}
+htool_hmatrix *htool_distributed_hmatrix(htool_distributed *d) { return d->hmat; }
+htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *) { return nullptr; }
+void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols) {
+    *rows = d->tc->n_points;
+    *cols = d->sc->n_points;
+}
+
+static void distributed_product(const htool_distributed *d, const void *x, void *y) {
+    const HMatrix &H = d->hmat->H;
+    const size_t es = H.is_complex ? 16 : 8;
+    const int nt = d->tc->n_points;
+    if (H.t_root == 0) { // one rank owning everything: plain user-numbered product
+        device_matvec_host(H, x, y);
+        return;
+    }
+    std::vector<char> local((size_t)H.row_size * es), full((size_t)nt * es);
+    device_matvec_host(H, x, local.data()); // local rows, cluster order
+    std::vector<int64_t> cb(d->counts.size()), db(d->displs.size());
+    for (size_t p = 0; p < cb.size(); p++) { cb[p] = d->counts[p] * (int64_t)es; db[p] = d->displs[p] * (int64_t)es; }
+    HM_CHECK(d->comm.allgatherv != nullptr, "communicator has no allgatherv");
+    int rc = d->comm.allgatherv(d->comm.ctx, local.data(), (int64_t)local.size(), full.data(), cb.data(), db.data());
+    HM_CHECK(rc == 0, "allgatherv failed");
+    for (int i = 0; i < nt; i++) std::memcpy((char *)y + (size_t)d->tc->perm[i] * es, &full[(size_t)i * es], es);
+}
+
+int htool_distributed_matvec(const htool_distributed *d, const void *x, void *y) {
+    API_BEGIN
+    distributed_product(d, x, y);
+    API_END
+}
+int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, void *Y) {
+    API_BEGIN
+    const size_t es = d->hmat->H.is_complex ? 16 : 8;
+    const size_t nin = (size_t)d->sc->n_points, nout = (size_t)d->tc->n_points;
+    for (int c = 0; c < mu; c++) distributed_product(d, (const char *)X + c * nin * es, (char *)Y + c * nout * es);
+    API_END
+}
+}

@@ -1,0 +1,283 @@
+// cluster.cpp -- geometric cluster tree, built level by level (OpenMP over the nodes of a level).
+//
+// Replaces htool::ClusterTreeBuilder<double>::create_cluster_tree as called from
+// src/htool/clustering/cluster_tree_builder.hpp:23,39,56 (lib/htool itself is not vendored;
+// algorithm per SURVEY.md Appendix A.2):
+//   centre = weighted mean, radius = max(|p - c| + radii), split direction = principal axis of
+//   the weighted covariance (PCA*) or longest bounding-box edge (BoundingBox*), points sorted
+//   along it and cut in equal counts (Regular) or equal widths (Geometric); a node stays a leaf
+//   when a child would be smaller than maximal_leaf_size; depth-1 children are the partition.
+#include "cluster.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace hm {
+
+ClusterHandle *ClusterTree::handle(int node) {
+    if (handles.size() < offset.size()) handles.resize(offset.size());
+    if (!handles[node]) handles[node].reset(new ClusterHandle{this, node});
+    return handles[node].get();
+}
+
+namespace {
+
+struct Geometry {
+    double c[3];
+    double radius;
+};
+
+Geometry compute_geometry(const ClusterTree &T, const double *radii, const double *weights, int off, int sz) {
+    const int d = T.dim;
+    Geometry g{{0, 0, 0}, 0};
+    double wsum = 0;
+    for (int i = 0; i < sz; i++) {
+        int u = T.perm[off + i];
+        double w = weights ? weights[u] : 1.0;
+        wsum += w;
+        for (int k = 0; k < d; k++) g.c[k] += w * T.coords[(size_t)u * d + k];
+    }
+    if (wsum != 0)
+        for (int k = 0; k < d; k++) g.c[k] /= wsum;
+    for (int i = 0; i < sz; i++) {
+        int u = T.perm[off + i];
+        double s = 0;
+        for (int k = 0; k < d; k++) {
+            double t = T.coords[(size_t)u * d + k] - g.c[k];
+            s += t * t;
+        }
+        double r = std::sqrt(s) + (radii ? radii[u] : 0.0);
+        if (r > g.radius) g.radius = r;
+    }
+    return g;
+}
+
+// dominant eigenvector of a symmetric d x d matrix (d <= 3), cyclic Jacobi
+void dominant_axis(double a[3][3], int d, double dir[3]) {
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 50; sweep++) {
+        double off = 0;
+        for (int i = 0; i < d; i++)
+            for (int j = i + 1; j < d; j++) off += a[i][j] * a[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < d; p++)
+            for (int q = p + 1; q < d; q++) {
+                if (std::fabs(a[p][q]) < 1e-300) continue;
+                double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1));
+                double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+                for (int k = 0; k < d; k++) {
+                    double x = a[k][p], y = a[k][q];
+                    a[k][p] = cs * x - sn * y;
+                    a[k][q] = sn * x + cs * y;
+                }
+                for (int k = 0; k < d; k++) {
+                    double x = a[p][k], y = a[q][k];
+                    a[p][k] = cs * x - sn * y;
+                    a[q][k] = sn * x + cs * y;
+                }
+                for (int k = 0; k < d; k++) {
+                    double x = v[k][p], y = v[k][q];
+                    v[k][p] = cs * x - sn * y;
+                    v[k][q] = sn * x + cs * y;
+                }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < d; i++)
+        if (a[i][i] > a[best][best]) best = i;
+    for (int k = 0; k < 3; k++) dir[k] = k < d ? v[k][best] : 0.0;
+    for (int k = 0; k < d; k++)
+        if (std::fabs(dir[k]) > 1e-14) {
+            if (dir[k] < 0)
+                for (int q = 0; q < d; q++) dir[q] = -dir[q];
+            break;
+        }
+}
+
+// sorts perm[off, off+sz) along the split direction, returns the piece sizes
+std::vector<int> split_range(ClusterTree &T, const double *weights, int off, int sz, const double centre[3], int pieces, int strategy) {
+    const int d = T.dim;
+    double dir[3] = {1, 0, 0};
+    const bool pca = strategy == 0 || strategy == 1, regular = strategy == 0 || strategy == 2;
+    if (pca) {
+        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int i = 0; i < sz; i++) {
+            int u = T.perm[off + i];
+            double w = weights ? weights[u] : 1.0, t[3];
+            for (int k = 0; k < d; k++) t[k] = T.coords[(size_t)u * d + k] - centre[k];
+            for (int p = 0; p < d; p++)
+                for (int q = 0; q < d; q++) cov[p][q] += w * t[p] * t[q];
+        }
+        dominant_axis(cov, d, dir);
+    } else {
+        double lo[3], hi[3];
+        for (int k = 0; k < d; k++) lo[k] = 1e300, hi[k] = -1e300;
+        for (int i = 0; i < sz; i++) {
+            int u = T.perm[off + i];
+            for (int k = 0; k < d; k++) {
+                double x = T.coords[(size_t)u * d + k];
+                lo[k] = std::min(lo[k], x);
+                hi[k] = std::max(hi[k], x);
+            }
+        }
+        int best = 0;
+        for (int k = 1; k < d; k++)
+            if (hi[k] - lo[k] > hi[best] - lo[best]) best = k;
+        for (int k = 0; k < 3; k++) dir[k] = k == best;
+    }
+    std::vector<std::pair<double, int>> key(sz);
+    for (int i = 0; i < sz; i++) {
+        int u = T.perm[off + i];
+        double s = 0;
+        for (int k = 0; k < d; k++) s += (T.coords[(size_t)u * d + k] - centre[k]) * dir[k];
+        key[i] = std::make_pair(s, u);
+    }
+    std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
+    for (int i = 0; i < sz; i++) T.perm[off + i] = key[i].second;
+    std::vector<int> sizes(pieces, 0);
+    if (regular) {
+        int base = sz / pieces;
+        for (int p = 0; p < pieces; p++) sizes[p] = base;
+        sizes[pieces - 1] = sz - base * (pieces - 1);
+    } else {
+        double lo = key.front().first, hi = key.back().first, w = (hi - lo) / pieces;
+        int pos = 0;
+        for (int p = 0; p < pieces; p++) {
+            double cut = lo + w * (p + 1);
+            int start = pos;
+            if (p == pieces - 1)
+                pos = sz;
+            else
+                while (pos < sz && key[pos].first < cut) pos++;
+            sizes[p] = pos - start;
+        }
+    }
+    return sizes;
+}
+
+int push_node(ClusterTree &T, int off, int sz, int depth, int parent, int part, const Geometry &g) {
+    T.offset.push_back(off);
+    T.size.push_back(sz);
+    T.depth.push_back(depth);
+    T.parent.push_back(parent);
+    T.first_child.push_back(-1);
+    T.n_child.push_back(0);
+    T.partition.push_back(part);
+    T.cx.push_back(g.c[0]);
+    T.cy.push_back(g.c[1]);
+    T.cz.push_back(g.c[2]);
+    T.radius.push_back(g.radius);
+    return (int)T.offset.size() - 1;
+}
+
+} // namespace
+
+ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
+    HM_CHECK(a.dim >= 1 && a.dim <= 3, "cluster tree: spatial dimension must be 1, 2 or 3");
+    HM_CHECK(a.n_points > 0, "cluster tree: no points");
+    HM_CHECK(a.n_children >= 2, "cluster tree: number_of_children must be >= 2");
+    std::unique_ptr<ClusterTree> Tp(new ClusterTree);
+    ClusterTree &T = *Tp;
+    T.n_points = a.n_points;
+    T.dim = a.dim;
+    T.max_leaf = a.max_leaf;
+    T.n_children = a.n_children;
+    T.n_partition = a.size_of_partition < 1 ? 1 : a.size_of_partition;
+    T.coords.assign(a.coords, a.coords + (size_t)a.n_points * a.dim);
+    T.perm.resize(a.n_points);
+    std::iota(T.perm.begin(), T.perm.end(), 0);
+    const int P = T.n_partition;
+
+    Geometry g0 = compute_geometry(T, a.radii, a.weights, 0, a.n_points);
+    push_node(T, 0, a.n_points, 0, -1, -1, g0);
+    std::vector<int> level; // nodes to try to split next
+    if (P == 1) {
+        T.partition[0] = 0;
+        T.part_nodes.push_back(0);
+        level.push_back(0);
+    } else {
+        std::vector<int> sizes;
+        if (a.partition && a.partition_is_local) {
+            int total = 0;
+            for (int p = 0; p < P; p++) {
+                HM_CHECK(a.partition[2 * p] == total, "Wrong format for partition");
+                sizes.push_back(a.partition[2 * p + 1]);
+                total += a.partition[2 * p + 1];
+            }
+            HM_CHECK(total == a.n_points, "Wrong format for partition");
+        } else if (a.partition) {
+            sizes.assign(P, 0);
+            for (int i = 0; i < a.n_points; i++) {
+                HM_CHECK(a.partition[i] >= 0 && a.partition[i] < P, "Wrong format for partition");
+                sizes[a.partition[i]]++;
+            }
+            std::vector<int> start(P, 0), np(a.n_points);
+            for (int p = 1; p < P; p++) start[p] = start[p - 1] + sizes[p - 1];
+            for (int i = 0; i < a.n_points; i++) np[start[a.partition[i]]++] = i;
+            T.perm.swap(np);
+        } else {
+            sizes = split_range(T, a.weights, 0, a.n_points, g0.c, P, a.strategy);
+        }
+        T.first_child[0] = 1;
+        T.n_child[0] = P;
+        int off = 0;
+        for (int p = 0; p < P; p++) {
+            Geometry g = compute_geometry(T, a.radii, a.weights, off, sizes[p]);
+            int id = push_node(T, off, sizes[p], 1, 0, p, g);
+            T.part_nodes.push_back(id);
+            level.push_back(id);
+            off += sizes[p];
+        }
+    }
+
+    struct Split {
+        bool ok;
+        std::vector<int> sizes;
+        std::vector<Geometry> geo;
+    };
+    const int nc = a.n_children;
+    while (!level.empty()) {
+        std::vector<Split> res(level.size());
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long q = 0; q < (long)level.size(); q++) {
+            int id = level[q], off = T.offset[id], sz = T.size[id];
+            Split &s = res[q];
+            s.ok = false;
+            if (sz / nc < T.max_leaf) continue;
+            std::vector<int> saved(T.perm.begin() + off, T.perm.begin() + off + sz);
+            double c[3] = {T.cx[id], T.cy[id], T.cz[id]};
+            s.sizes = split_range(T, a.weights, off, sz, c, nc, a.strategy);
+            bool small = false;
+            for (int v : s.sizes)
+                if (v < T.max_leaf) small = true;
+            if (small) {
+                std::copy(saved.begin(), saved.end(), T.perm.begin() + off);
+                continue;
+            }
+            s.ok = true;
+            int o = off;
+            for (int v : s.sizes) {
+                s.geo.push_back(compute_geometry(T, a.radii, a.weights, o, v));
+                o += v;
+            }
+        }
+        std::vector<int> next;
+        for (size_t q = 0; q < level.size(); q++) {
+            if (!res[q].ok) continue;
+            int id = level[q], o = T.offset[id];
+            T.first_child[id] = (int)T.offset.size();
+            T.n_child[id] = nc;
+            for (int p = 0; p < nc; p++) {
+                int ch = push_node(T, o, res[q].sizes[p], T.depth[id] + 1, id, T.partition[id], res[q].geo[p]);
+                next.push_back(ch);
+                o += res[q].sizes[p];
+            }
+        }
+        level.swap(next);
+    }
+    return Tp.release();
+}
+
+} // namespace hm

@@ -1,0 +1,746 @@
+// device.hip -- gfx950 kernels of the H-matrix product and of the panel pack, plus their drivers.
+//
+// The H-matvec (replaces htool::add_hmatrix_vector_product as called from
+// src/htool/hmatrix/hmatrix.hpp:113) is HBM-bound: 2 flops per 8-byte panel element.  It runs as
+// four launches over the tile-major layout of hmatrix.hpp:
+//   gather_x        W[0:n)   = x[perm_s]                       (user -> cluster numbering)
+//   tile_gemv_tall  R        = V-panels * x        (phase A,  one workgroup per source tile)
+//   tile_gemv_tall  t        = sum of partials     (phase A2, only leaves spanning several tiles)
+//   tile_gemv_wide  y[perm_t]= [U|D]-panels * W[.] (phase B,  one workgroup per row tile)
+// Every workgroup streams one contiguous panel with 16-byte loads per lane (64 lanes = 1 KiB per
+// wave instruction), 16 loads in flight per wave; coefficients are fetched once per 16/64 columns
+// and broadcast with v_readlane; sums are formed in a fixed order (no atomics), so the product is
+// bitwise reproducible.
+#include "device_internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace hm {
+
+// ------------------------------------------------------------------------------------------------
+// element traits: a lane always moves one double2 (two real rows, or one complex entry)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+struct RealOps {
+    typedef double T;
+    static constexpr int RPL = 2; // rows per lane
+    static __device__ __forceinline__ T zero() { return 0.0; }
+    static __device__ __forceinline__ T one() { return 1.0; }
+    static __device__ __forceinline__ T bcast(T v, int src) { return bcast_f64(v, src); }
+    static __device__ __forceinline__ void fma(double2 &acc, const double2 v, const T w) {
+        acc.x = ::fma(v.x, w, acc.x);
+        acc.y = ::fma(v.y, w, acc.y);
+    }
+};
+
+struct CplxOps {
+    typedef double2 T;
+    static constexpr int RPL = 1;
+    static __device__ __forceinline__ T zero() { return make_double2(0.0, 0.0); }
+    static __device__ __forceinline__ T one() { return make_double2(1.0, 0.0); }
+    static __device__ __forceinline__ T bcast(T v, int src) { return make_double2(bcast_f64(v.x, src), bcast_f64(v.y, src)); }
+    static __device__ __forceinline__ void fma(double2 &acc, const double2 v, const T w) {
+        acc.x = ::fma(v.x, w.x, ::fma(-v.y, w.y, acc.x));
+        acc.y = ::fma(v.x, w.y, ::fma(v.y, w.x, acc.y));
+    }
+};
+
+template <typename Ops>
+__device__ __forceinline__ void store_rows(typename Ops::T *out, const GTile &tl, int row0, int nrows_total, const double2 acc) {
+    if (Ops::RPL == 2) {
+        double *o = (double *)out;
+        if (row0 < nrows_total) o[tl.omap ? (long long)tl.omap[row0] : tl.out_begin + row0] = acc.x;
+        if (row0 + 1 < nrows_total) o[tl.omap ? (long long)tl.omap[row0 + 1] : tl.out_begin + row0 + 1] = acc.y;
+    } else {
+        double2 *o = (double2 *)out;
+        if (row0 < nrows_total) o[tl.omap ? (long long)tl.omap[row0] : tl.out_begin + row0] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase B: few rows (<= 64*RPL), many columns; the four waves split the columns, LDS combine.
+// ------------------------------------------------------------------------------------------------
+template <typename Ops, int CH>
+__global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
+                                                      const typename Ops::T *__restrict__ W, typename Ops::T *__restrict__ out) {
+    typedef typename Ops::T T;
+    const GTile tl = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = lane * Ops::RPL;
+    const bool active = row0 < tl.nrows;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int s = 0; s < tl.nseg; s++) {
+        const GSeg sg = segs[tl.seg_begin + s];
+        const T *base = (const T *)sg.panel + row0;
+        const long long ld = sg.ld_last;
+        const int ncols = sg.ncols;
+        for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
+            const int nc = min(CH, ncols - c0);
+            T coef = Ops::zero();
+            if (lane < nc) coef = W[sg.cidx[c0 + lane]];
+            const T *p = base + (long long)c0 * ld;
+            if (nc == CH) {
+                double2 v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) v[u] = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < CH; u++) Ops::fma(acc, v[u], Ops::bcast(coef, u));
+            } else {
+                for (int u = 0; u < nc; u++) {
+                    double2 v = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+                    Ops::fma(acc, v, Ops::bcast(coef, u));
+                }
+            }
+        }
+    }
+    __shared__ double2 red[4][64];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        double2 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+        double2 sum = make_double2(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y);
+        store_rows<Ops>(out, tl, row0, tl.nrows, sum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase A / A2: many rows (cut in chunks of 64*RPL), few columns; each wave owns whole row chunks.
+// ------------------------------------------------------------------------------------------------
+template <typename Ops, int CH>
+__global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
+                                                      const typename Ops::T *W, typename Ops::T *out) { // W and out alias (disjoint regions)
+    typedef typename Ops::T T;
+    constexpr int TM = 64 * Ops::RPL;
+    const GTile tl = tiles[blockIdx.x];
+    const GSeg sg = segs[tl.seg_begin];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = lane * Ops::RPL;
+    const int nq = (tl.nrows + TM - 1) / TM;
+    const int ncols = sg.ncols;
+    for (int q = wave; q < nq; q += 4) {
+        const int rows_here = min(TM, tl.nrows - q * TM);
+        const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
+        const bool active = row0 < rows_here;
+        const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int c0 = 0; c0 < ncols; c0 += 64) {
+            const int nc = min(64, ncols - c0);
+            T coef = Ops::zero();
+            if (lane < nc) coef = W[sg.cidx[c0 + lane]];
+            for (int cc = 0; cc < nc; cc += CH) {
+                const T *p = base + (long long)(c0 + cc) * ld;
+                if (cc + CH <= nc) {
+                    double2 v[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; u++) v[u] = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < CH; u++) Ops::fma(acc, v[u], Ops::bcast(coef, cc + u));
+                } else {
+                    for (int u = 0; cc + u < nc; u++) {
+                        double2 v = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+                        Ops::fma(acc, v, Ops::bcast(coef, cc + u));
+                    }
+                }
+            }
+        }
+        store_rows<Ops>(out, tl, q * TM + row0, tl.nrows, acc);
+    }
+}
+
+template <typename T>
+__global__ void gather_x_kernel(const T *__restrict__ x, const int *__restrict__ perm, T *__restrict__ W, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) W[i] = x[perm[i]];
+}
+
+template <typename T>
+__global__ void set_one_kernel(T *W, long long idx, T one) { W[idx] = one; }
+
+// ------------------------------------------------------------------------------------------------
+// native generators evaluated on device (cluster-ordered SoA coordinates: x[0:n) y[0:n) z[0:n))
+// Same operation order as the CPU restatement (fma chain, sqrt, one division).
+// ------------------------------------------------------------------------------------------------
+struct DevGen {
+    int kind, dim;
+    double param;
+    const double *tc; // 3*nt
+    const double *sc; // 3*ns
+    int nt, ns;
+};
+
+__device__ __forceinline__ double gen_dist(const DevGen &g, int i, int j) {
+    double s = 0;
+    for (int k = 0; k < g.dim; k++) {
+        double t = g.tc[(long long)k * g.nt + i] - g.sc[(long long)k * g.ns + j];
+        s = ::fma(t, t, s);
+    }
+    return sqrt(s);
+}
+__device__ __forceinline__ void gen_eval(const DevGen &g, int i, int j, double &out) {
+    double r = gen_dist(g, i, j);
+    if (g.kind == 0) out = 1.0 / (g.param + r);
+    else out = r > 0 ? 1.0 / (4 * M_PI * r) : 0.0;
+}
+__device__ __forceinline__ void gen_eval(const DevGen &g, int i, int j, double2 &out) {
+    double r = gen_dist(g, i, j);
+    if (g.kind == 2) {
+        if (r > 0) {
+            double s, c;
+            sincos(g.param * r, &s, &c);
+            double q = 1.0 / (4 * M_PI * r);
+            out = make_double2(c * q, s * q);
+        } else out = make_double2(0.0, 0.0);
+    } else {
+        double v;
+        gen_eval(g, i, j, v);
+        out = make_double2(v, 0.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: scatter the per-leaf panels of the temporary arena into the tile-major panels
+// ------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const DevBlock *blocks;
+    const int *item_block, *item_tile;
+    const int *tile_off, *tile_size;
+    const int *tile_n;         // b_ncols (phase B) / a_nrows (phase A) of the tile
+    const long long *tile_pbase, *tile_ibase;
+    void *panel;
+    int *index;                // cidxB / oidxA
+    const void *arena;
+    int vec_rows, tile_max;
+    int eval_dense;            // dense leaves are evaluated from gen instead of copied
+    DevGen gen;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_u_kernel(PackArgs a) {
+    const int it = blockIdx.x;
+    const DevBlock b = a.blocks[a.item_block[it]];
+    const int r = a.item_tile[it];
+    const int toff = a.tile_off[r], ts = a.tile_size[r];
+    const int ld = (ts + a.vec_rows - 1) / a.vec_rows * a.vec_rows;
+    const int ncols = b.rank >= 0 ? b.rank : b.n;
+    T *dst = (T *)a.panel + a.tile_pbase[r] + (long long)b.ucol * ld;
+    int *cidx = a.index + a.tile_ibase[r] + b.ucol;
+    const T *src = (const T *)a.arena + b.tmp_u + (toff - b.t_off);
+    const int total = ncols * ld;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int k = e / ld, i = e - k * ld;
+        T v;
+        if (i >= ts) v = T{};
+        else if (b.rank < 0 && a.eval_dense) gen_eval(a.gen, toff + i, b.s_off + k, v);
+        else v = src[(long long)k * b.m + i];
+        dst[(long long)k * ld + i] = v;
+        if (i == 0) cidx[k] = b.rank >= 0 ? (int)(b.tpos + k) : b.s_off + k;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_v_kernel(PackArgs a) {
+    const int it = blockIdx.x;
+    const DevBlock b = a.blocks[a.item_block[it]];
+    const int c = a.item_tile[it];
+    const int coff = a.tile_off[c], cs = a.tile_size[c];
+    const int TM = a.tile_max;
+    const int nrows = a.tile_n[c];
+    const int nq = (nrows + TM - 1) / TM;
+    const int rem = nrows - (nq - 1) * TM;
+    const int ld_last = (rem + a.vec_rows - 1) / a.vec_rows * a.vec_rows;
+    T *dst = (T *)a.panel + a.tile_pbase[c];
+    int *oidx = a.index + a.tile_ibase[c] + b.vcol;
+    const T *src = (const T *)a.arena + b.tmp_v + (coff - b.s_off);
+    const int p = c - b.v_tile0;
+    const int total = b.rank * cs;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int j = e / b.rank, k = e - j * b.rank;
+        int rr = b.vcol + k, q = rr / TM, rl = rr - q * TM;
+        int ld = (q == nq - 1) ? ld_last : TM;
+        dst[(long long)q * cs * TM + (long long)j * ld + rl] = src[(long long)k * b.n + j];
+        if (j == 0) oidx[k] = (int)(b.v_obase + (long long)p * b.v_ostride + k);
+    }
+}
+
+// zero the padding rows of the last row chunk of phase-A panels (ld_last > rem) is not needed: the
+// padding rows are never stored.  Phase-B panels pad inside pack_u (i >= ts -> 0).
+
+// unpack one leaf for introspection (inverse of pack)
+template <typename T>
+__global__ void unpack_u_kernel(PackArgs a, T *out) {
+    const DevBlock b = a.blocks[0];
+    const int r = a.item_tile[blockIdx.x];
+    const int toff = a.tile_off[r], ts = a.tile_size[r];
+    const int ld = (ts + a.vec_rows - 1) / a.vec_rows * a.vec_rows;
+    const int ncols = b.rank >= 0 ? b.rank : b.n;
+    const T *src = (const T *)a.panel + a.tile_pbase[r] + (long long)b.ucol * ld;
+    for (int e = threadIdx.x; e < ncols * ts; e += blockDim.x) {
+        int k = e / ts, i = e - k * ts;
+        out[(long long)k * b.m + (toff - b.t_off) + i] = src[(long long)k * ld + i];
+    }
+}
+template <typename T>
+__global__ void unpack_v_kernel(PackArgs a, T *out) {
+    const DevBlock b = a.blocks[0];
+    const int c = a.item_tile[blockIdx.x];
+    const int coff = a.tile_off[c], cs = a.tile_size[c];
+    const int TM = a.tile_max;
+    const int nrows = a.tile_n[c];
+    const int nq = (nrows + TM - 1) / TM;
+    const int rem = nrows - (nq - 1) * TM;
+    const int ld_last = (rem + a.vec_rows - 1) / a.vec_rows * a.vec_rows;
+    const T *src = (const T *)a.panel + a.tile_pbase[c];
+    for (int e = threadIdx.x; e < b.rank * cs; e += blockDim.x) {
+        int j = e / b.rank, k = e - j * b.rank;
+        int rr = b.vcol + k, q = rr / TM, rl = rr - q * TM;
+        int ld = (q == nq - 1) ? ld_last : TM;
+        out[(long long)((coff - b.s_off) + j) * b.rank + k] = src[(long long)q * cs * TM + (long long)j * ld + rl];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side drivers
+// ------------------------------------------------------------------------------------------------
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+static int g_device = 0;
+void device_select(int dev) {
+    HIP_OK(hipSetDevice(dev));
+    g_device = dev;
+}
+
+std::string device_name() {
+    if (device_count() == 0) return "";
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, g_device) != hipSuccess) return "";
+    return std::string(p.gcnArchName) + ":" + p.name;
+}
+
+static void require_device() {
+    HM_CHECK(device_count() > 0, "no HIP device available: libhtool_mi355x has no CPU fallback (HIP path required)");
+    HIP_OK(hipSetDevice(g_device));
+}
+
+template <typename V>
+static V *upload(const std::vector<V> &h, size_t *bytes = nullptr) {
+    V *d = nullptr;
+    size_t n = std::max<size_t>(h.size(), 1) * sizeof(V);
+    HIP_OK(hipMalloc((void **)&d, n));
+    if (!h.empty()) HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+    if (bytes) *bytes += n;
+    return d;
+}
+
+static DevBlock to_dev(const BlockRec &b, const HMatrix &H) {
+    DevBlock d;
+    d.tmp_u = b.tmp_u; d.tmp_v = b.tmp_v; d.tpos = b.tpos; d.v_obase = b.v_obase;
+    d.t_off = b.t_off; d.m = b.m; d.s_off = b.s_off; d.n = b.n; d.rank = b.rank; d.cap = b.cap;
+    d.ucol = b.ucol; d.vcol = b.vcol; d.v_ostride = b.v_ostride;
+    d.v_tile0 = H.ctiles.node_tile_begin[b.s_node];
+    d.status = b.status; d.pad_ = 0;
+    return d;
+}
+
+struct DeviceBuilder {
+    HMatrix &H;
+    DeviceHMatrix *D;
+    int vec_rows;
+    int *d_rt_off = nullptr, *d_rt_size = nullptr, *d_ct_off = nullptr, *d_ct_size = nullptr;
+    DevGen gen{};
+    bool have_gen = false;
+
+    explicit DeviceBuilder(HMatrix &h) : H(h) {
+        require_device();
+        D = new DeviceHMatrix;
+        H.dev = D;
+        D->device = g_device;
+        D->is_complex = H.is_complex;
+        D->esize = H.is_complex ? 16 : 8;
+        vec_rows = H.is_complex ? 1 : 2;
+        D->n_source = H.sc->n_points;
+        D->n_target = H.tc->n_points;
+        D->row_off = H.row_off;
+        D->row_size = H.row_size;
+        HIP_OK(hipStreamCreate(&D->stream));
+        HIP_OK(hipEventCreate(&D->ev0));
+        HIP_OK(hipEventCreate(&D->ev1));
+        d_rt_off = upload(H.rtiles.off);
+        d_rt_size = upload(H.rtiles.size);
+        d_ct_off = upload(H.ctiles.off);
+        d_ct_size = upload(H.ctiles.size);
+    }
+    ~DeviceBuilder() {
+        (void)hipFree(d_rt_off); (void)hipFree(d_rt_size); (void)hipFree(d_ct_off); (void)hipFree(d_ct_size);
+    }
+
+    // pack one batch whose leaf panels sit in d_arena (device)
+    template <typename T>
+    void pack_batch(const std::vector<int64_t> &batch_blocks, const void *d_arena, bool eval_dense) {
+        BatchLayout L;
+        L.batch_id = (int)D->batches.size();
+        compute_batch_layout(H, batch_blocks, vec_rows, L);
+        for (int64_t bi : batch_blocks) H.blocks[bi].batch = L.batch_id;
+        DevBatch B;
+        size_t szB = std::max<int64_t>(L.panelB_elems, 1) * sizeof(T), szA = std::max<int64_t>(L.panelA_elems, 1) * sizeof(T);
+        HIP_OK(hipMalloc(&B.panelB, szB));
+        HIP_OK(hipMalloc(&B.panelA, szA));
+        HIP_OK(hipMalloc((void **)&B.cidxB, std::max<int64_t>(L.cidxB_elems, 1) * sizeof(int)));
+        HIP_OK(hipMalloc((void **)&B.oidxA, std::max<int64_t>(L.oidxA_elems, 1) * sizeof(int)));
+        B.bytes = szB + szA + (L.cidxB_elems + L.oidxA_elems) * sizeof(int);
+        std::vector<DevBlock> hb(batch_blocks.size());
+        for (size_t q = 0; q < batch_blocks.size(); q++) hb[q] = to_dev(H.blocks[batch_blocks[q]], H);
+        DevBlock *d_blocks = upload(hb);
+        int *d_ub = upload(L.u_item_block), *d_ut = upload(L.u_item_tile), *d_vb = upload(L.v_item_block), *d_vt = upload(L.v_item_tile);
+        int *d_bn = upload(L.b_ncols), *d_an = upload(L.a_nrows);
+        std::vector<long long> t1(L.b_pbase.begin(), L.b_pbase.end()), t2(L.b_cbase.begin(), L.b_cbase.end());
+        std::vector<long long> t3(L.a_pbase.begin(), L.a_pbase.end()), t4(L.a_obase.begin(), L.a_obase.end());
+        long long *d_bp = upload(t1), *d_bc = upload(t2), *d_ap = upload(t3), *d_ao = upload(t4);
+        PackArgs a;
+        a.blocks = d_blocks; a.arena = d_arena; a.vec_rows = vec_rows; a.tile_max = H.tile_max;
+        a.eval_dense = eval_dense ? 1 : 0; a.gen = gen;
+        // U / dense side
+        a.item_block = d_ub; a.item_tile = d_ut; a.tile_off = d_rt_off; a.tile_size = d_rt_size; a.tile_n = d_bn;
+        a.tile_pbase = d_bp; a.tile_ibase = d_bc; a.panel = B.panelB; a.index = B.cidxB;
+        if (!L.u_item_block.empty()) hipLaunchKernelGGL(pack_u_kernel<T>, dim3((unsigned)L.u_item_block.size()), dim3(256), 0, D->stream, a);
+        // V side
+        a.item_block = d_vb; a.item_tile = d_vt; a.tile_off = d_ct_off; a.tile_size = d_ct_size; a.tile_n = d_an;
+        a.tile_pbase = d_ap; a.tile_ibase = d_ao; a.panel = B.panelA; a.index = B.oidxA;
+        if (!L.v_item_block.empty()) hipLaunchKernelGGL(pack_v_kernel<T>, dim3((unsigned)L.v_item_block.size()), dim3(256), 0, D->stream, a);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(D->stream));
+        for (void *p : {(void *)d_blocks, (void *)d_ub, (void *)d_ut, (void *)d_vb, (void *)d_vt, (void *)d_bn, (void *)d_an, (void *)d_bp, (void *)d_bc, (void *)d_ap, (void *)d_ao}) (void)hipFree(p);
+        D->batches.push_back(B);
+        BatchTables bt;
+        bt.b_ncols.swap(L.b_ncols); bt.a_nrows.swap(L.a_nrows);
+        bt.b_pbase.swap(L.b_pbase); bt.b_cbase.swap(L.b_cbase); bt.a_pbase.swap(L.a_pbase); bt.a_obase.swap(L.a_obase);
+        bt.reduces.swap(L.reduces);
+        D->tabs.push_back(std::move(bt));
+    }
+
+    // build W, the permutation tables and the tile/segment tables of the three product phases
+    template <typename T>
+    void assemble() {
+        const ClusterTree &Tt = *H.tc, &Ss = *H.sc;
+        const int TM = H.tile_max, Ns = Ss.n_points;
+        std::vector<BatchTables> &tabs = D->tabs;
+        const long long r_start = (Ns + 1 + 1) / 2 * 2;
+        D->W_elems = r_start + H.r_elems + 2;
+        HIP_OK(hipMalloc(&D->W, D->W_elems * sizeof(T)));
+        HIP_OK(hipMemset(D->W, 0, D->W_elems * sizeof(T)));
+        T one;
+        std::memset(&one, 0, sizeof(T));
+        *(double *)&one = 1.0;
+        HIP_OK(hipMemcpy((char *)D->W + (size_t)Ns * sizeof(T), &one, sizeof(T), hipMemcpyHostToDevice));
+        D->perm_s = upload(Ss.perm, &D->table_bytes);
+        D->perm_t = upload(Tt.perm, &D->table_bytes);
+        std::vector<int> io(Ns);
+        std::iota(io.begin(), io.end(), 0);
+        D->iota = upload(io, &D->table_bytes);
+        int maxP = 1;
+        for (auto &bt : tabs) for (auto &r : bt.reduces) maxP = std::max(maxP, r.ncols);
+        std::vector<int> ones(maxP, Ns);
+        D->ones_idx = upload(ones, &D->table_bytes);
+        HIP_OK(hipMalloc(&D->x_tmp, (size_t)std::max(Ns, 1) * sizeof(T)));
+        HIP_OK(hipMalloc(&D->y_tmp, (size_t)std::max(Tt.n_points, 1) * sizeof(T)));
+
+        std::vector<GSeg> segs;
+        std::vector<GTile> tB, tBc, tA, tA2;
+        std::vector<double> wB, wA, wA2; // work, for heavy-first ordering
+        const int nrt = H.rtiles.count(), nct = H.ctiles.count();
+        for (int r = 0; r < nrt; r++) {
+            GTile t;
+            t.seg_begin = (long long)segs.size();
+            t.nseg = 0;
+            t.nrows = H.rtiles.size[r];
+            int ld = (t.nrows + vec_rows - 1) / vec_rows * vec_rows;
+            double work = 0;
+            for (size_t b = 0; b < tabs.size(); b++) {
+                int nc = tabs[b].b_ncols[r];
+                if (nc == 0) continue;
+                GSeg s;
+                s.panel = (const char *)D->batches[b].panelB + (size_t)tabs[b].b_pbase[r] * sizeof(T);
+                s.cidx = D->batches[b].cidxB + tabs[b].b_cbase[r];
+                s.ncols = nc; s.ld_full = ld; s.ld_last = ld; s.pad_ = 0; s.chunk_stride = 0;
+                segs.push_back(s);
+                t.nseg++;
+                work += (double)nc * ld;
+            }
+            t.omap = D->perm_t + H.rtiles.off[r];
+            t.out_begin = 0;
+            tB.push_back(t);
+            GTile tc = t;
+            tc.omap = nullptr;
+            tc.out_begin = H.rtiles.off[r] - H.row_off;
+            tBc.push_back(tc);
+            wB.push_back(work);
+        }
+        for (size_t b = 0; b < tabs.size(); b++)
+            for (int c = 0; c < nct; c++) {
+                int nr = tabs[b].a_nrows[c];
+                if (nr == 0) continue;
+                int nq = (nr + TM - 1) / TM, rem = nr - (nq - 1) * TM;
+                GSeg s;
+                s.panel = (const char *)D->batches[b].panelA + (size_t)tabs[b].a_pbase[c] * sizeof(T);
+                s.cidx = D->iota + H.ctiles.off[c];
+                s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.pad_ = 0;
+                s.chunk_stride = (long long)H.ctiles.size[c] * TM;
+                GTile t;
+                t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = nr;
+                t.omap = D->batches[b].oidxA + tabs[b].a_obase[c]; t.out_begin = 0;
+                segs.push_back(s);
+                tA.push_back(t);
+                wA.push_back((double)nr * s.ncols);
+            }
+        for (size_t b = 0; b < tabs.size(); b++)
+            for (auto &r : tabs[b].reduces) {
+                GSeg s;
+                s.panel = (const char *)D->W + (size_t)r.w_panel * sizeof(T);
+                s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.pad_ = 0; s.chunk_stride = TM;
+                GTile t;
+                t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = r.nrows; t.omap = nullptr; t.out_begin = r.out_base;
+                segs.push_back(s);
+                tA2.push_back(t);
+                wA2.push_back((double)r.nrows * r.ncols);
+            }
+        auto sort_heavy = [](std::vector<GTile> &t, const std::vector<double> &w, std::vector<GTile> *twin) {
+            std::vector<int> idx(t.size());
+            std::iota(idx.begin(), idx.end(), 0);
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return w[a] > w[b]; });
+            std::vector<GTile> o(t.size()), o2(t.size());
+            for (size_t i = 0; i < idx.size(); i++) { o[i] = t[idx[i]]; if (twin) o2[i] = (*twin)[idx[i]]; }
+            t.swap(o);
+            if (twin) twin->swap(o2);
+        };
+        sort_heavy(tB, wB, &tBc);
+        sort_heavy(tA, wA, nullptr);
+        sort_heavy(tA2, wA2, nullptr);
+        D->segs = upload(segs, &D->table_bytes);
+        D->tilesB_user = upload(tB, &D->table_bytes);
+        D->tilesB_cluster = upload(tBc, &D->table_bytes);
+        D->tilesA = upload(tA, &D->table_bytes);
+        D->tilesA2 = upload(tA2, &D->table_bytes);
+        D->nB = (int)tB.size(); D->nA = (int)tA.size(); D->nA2 = (int)tA2.size();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems) {
+    DeviceBuilder db(H);
+    size_t es = H.is_complex ? 16 : 8;
+    void *d_arena = nullptr;
+    HIP_OK(hipMalloc(&d_arena, std::max<int64_t>(arena_elems, 1) * es));
+    if (arena_elems) HIP_OK(hipMemcpy(d_arena, arena, arena_elems * es, hipMemcpyHostToDevice));
+    std::vector<int64_t> all;
+    for (size_t i = 0; i < H.blocks.size(); i++) if (H.blocks[i].rank != 0) all.push_back((int64_t)i);
+    if (H.is_complex) db.pack_batch<double2>(all, d_arena, false);
+    else db.pack_batch<double>(all, d_arena, false);
+    HIP_OK(hipFree(d_arena));
+    if (H.is_complex) db.assemble<double2>();
+    else db.assemble<double>();
+    H.n_batches = (int)db.D->batches.size();
+}
+
+template <typename Ops>
+static void launch_product(const DeviceHMatrix *D, const void *x_dev, void *y_dev, int numbering, hipStream_t st) {
+    typedef typename Ops::T T;
+    T *W = (T *)D->W;
+    const int Ns = D->n_source;
+    if (numbering == 0) {
+        if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, D->perm_s, W, Ns);
+    } else {
+        HIP_OK(hipMemcpyAsync(W, x_dev, (size_t)Ns * sizeof(T), hipMemcpyDeviceToDevice, st));
+    }
+    if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W);
+    if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W);
+    if (D->nB) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev);
+    HIP_OK(hipGetLastError());
+}
+
+void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream) {
+    DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HIP_OK(hipSetDevice(D->device));
+    hipStream_t st = stream ? (hipStream_t)stream : D->stream;
+    HIP_OK(hipEventRecord(D->ev0, st));
+    if (D->is_complex) launch_product<CplxOps>(D, x_dev, y_dev, numbering, st);
+    else launch_product<RealOps>(D, x_dev, y_dev, numbering, st);
+    HIP_OK(hipEventRecord(D->ev1, st));
+}
+
+void device_matvec_host(const HMatrix &H, const void *x, void *y) {
+    DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HIP_OK(hipSetDevice(D->device));
+    const size_t es = D->esize;
+    HIP_OK(hipMemcpyAsync(D->x_tmp, x, (size_t)D->n_source * es, hipMemcpyHostToDevice, D->stream));
+    // a matrix built on the whole target cluster answers in user numbering; one built on a partition
+    // answers with its local rows in cluster order
+    const bool whole = H.t_root == 0;
+    device_matvec_device(H, D->x_tmp, D->y_tmp, whole ? 0 : 1, D->stream);
+    HIP_OK(hipMemcpyAsync(y, D->y_tmp, (size_t)(whole ? D->n_target : D->row_size) * es, hipMemcpyDeviceToHost, D->stream));
+    HIP_OK(hipStreamSynchronize(D->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, D->ev0, D->ev1) == hipSuccess) D->last_us = ms * 1e3;
+}
+
+double device_last_product_us(const HMatrix &H) {
+    if (!H.dev) return -1;
+    float ms = 0;
+    if (hipEventQuery(H.dev->ev1) == hipSuccess && hipEventElapsedTime(&ms, H.dev->ev0, H.dev->ev1) == hipSuccess) return ms * 1e3;
+    return H.dev->last_us;
+}
+
+int64_t device_resident_bytes(const HMatrix &H) {
+    if (!H.dev) return 0;
+    size_t b = H.dev->table_bytes + (size_t)H.dev->W_elems * H.dev->esize;
+    for (auto &B : H.dev->batches) b += B.bytes;
+    return (int64_t)b;
+}
+
+void device_free(DeviceHMatrix *D) {
+    if (!D) return;
+    (void)hipSetDevice(D->device);
+    for (auto &B : D->batches) { (void)hipFree(B.panelB); (void)hipFree(B.panelA); (void)hipFree(B.cidxB); (void)hipFree(B.oidxA); }
+    for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
+                    (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord})
+        if (p) (void)hipFree(p);
+    if (D->ev0) (void)hipEventDestroy(D->ev0);
+    if (D->ev1) (void)hipEventDestroy(D->ev1);
+    if (D->stream) (void)hipStreamDestroy(D->stream);
+    delete D;
+}
+
+// deep copy: new panels, tables re-assembled against the new buffers (hmatrix.hpp:48 __deepcopy__)
+void device_clone(const HMatrix &src, HMatrix &dst) {
+    const DeviceHMatrix *S = src.dev;
+    HM_CHECK(S != nullptr, "H-matrix has no device data");
+    HIP_OK(hipSetDevice(S->device));
+    // Re-pack is not possible (the arena is gone), so copy buffers and relocate pointers in the tables.
+    DeviceHMatrix *D = new DeviceHMatrix(*S);
+    dst.dev = D;
+    D->stream = nullptr; D->ev0 = D->ev1 = nullptr;
+    HIP_OK(hipStreamCreate(&D->stream));
+    HIP_OK(hipEventCreate(&D->ev0));
+    HIP_OK(hipEventCreate(&D->ev1));
+    auto dup = [](const void *p, size_t bytes) -> void * {
+        void *q = nullptr;
+        HIP_OK(hipMalloc(&q, std::max<size_t>(bytes, 1)));
+        if (p && bytes) HIP_OK(hipMemcpy(q, p, bytes, hipMemcpyDeviceToDevice));
+        return q;
+    };
+    struct Range { const char *old_lo, *old_hi; char *neu; };
+    std::vector<Range> map;
+    const size_t es = S->esize;
+    // sizes of per-batch buffers are recomputed from the stored byte count split: keep it simple by
+    // querying the allocation sizes through hipMemPtrGetInfo
+    auto dup_alloc = [&](const void *p) -> void * {
+        if (!p) return nullptr;
+        size_t sz = 0;
+        HIP_OK(hipMemPtrGetInfo(const_cast<void *>(p), &sz));
+        void *q = dup(p, sz);
+        map.push_back({(const char *)p, (const char *)p + sz, (char *)q});
+        return q;
+    };
+    for (size_t b = 0; b < S->batches.size(); b++) {
+        D->batches[b].panelB = dup_alloc(S->batches[b].panelB);
+        D->batches[b].panelA = dup_alloc(S->batches[b].panelA);
+        D->batches[b].cidxB = (int *)dup_alloc(S->batches[b].cidxB);
+        D->batches[b].oidxA = (int *)dup_alloc(S->batches[b].oidxA);
+    }
+    D->W = dup_alloc(S->W);
+    D->perm_s = (int *)dup_alloc(S->perm_s);
+    D->perm_t = (int *)dup_alloc(S->perm_t);
+    D->iota = (int *)dup_alloc(S->iota);
+    D->ones_idx = (int *)dup_alloc(S->ones_idx);
+    D->x_tmp = dup_alloc(S->x_tmp);
+    D->y_tmp = dup_alloc(S->y_tmp);
+    D->tcoord = (double *)dup_alloc(S->tcoord);
+    D->scoord = (double *)dup_alloc(S->scoord);
+    auto reloc = [&](const void *p) -> const void * {
+        if (!p) return nullptr;
+        for (auto &r : map) if ((const char *)p >= r.old_lo && (const char *)p < r.old_hi) return r.neu + ((const char *)p - r.old_lo);
+        throw Error("device_clone: dangling table pointer");
+    };
+    // segment table
+    size_t seg_bytes = 0;
+    HIP_OK(hipMemPtrGetInfo(S->segs, &seg_bytes));
+    std::vector<GSeg> segs(seg_bytes / sizeof(GSeg));
+    HIP_OK(hipMemcpy(segs.data(), S->segs, segs.size() * sizeof(GSeg), hipMemcpyDeviceToHost));
+    int nseg_used = 0;
+    auto fix_tiles = [&](const GTile *d_src, int n, GTile **d_dst) {
+        std::vector<GTile> t((size_t)std::max(n, 0));
+        if (n) HIP_OK(hipMemcpy(t.data(), d_src, (size_t)n * sizeof(GTile), hipMemcpyDeviceToHost));
+        for (auto &x : t) { x.omap = (const int *)reloc(x.omap); nseg_used = std::max<long long>(nseg_used, x.seg_begin + x.nseg); }
+        *d_dst = upload(t);
+    };
+    fix_tiles(S->tilesB_user, S->nB, &D->tilesB_user);
+    fix_tiles(S->tilesB_cluster, S->nB, &D->tilesB_cluster);
+    fix_tiles(S->tilesA, S->nA, &D->tilesA);
+    fix_tiles(S->tilesA2, S->nA2, &D->tilesA2);
+    segs.resize((size_t)nseg_used);
+    for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); }
+    D->segs = upload(segs);
+    (void)es;
+}
+
+// panels of one leaf, copied back to the host (introspection / parity tests)
+void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *Bout) {
+    const DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HM_CHECK(leaf >= 0 && leaf < (int64_t)H.blocks.size(), "leaf index out of range");
+    HIP_OK(hipSetDevice(D->device));
+    const BlockRec &b = H.blocks[leaf];
+    if (b.rank == 0) return;
+    const size_t es = D->esize;
+    const int vec_rows = H.is_complex ? 1 : 2;
+    const BatchTables &L = D->tabs[b.batch];
+    std::vector<DevBlock> hb{to_dev(b, H)};
+    DevBlock *d_b = upload(hb);
+    PackArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.blocks = d_b; a.vec_rows = vec_rows; a.tile_max = H.tile_max;
+    std::vector<int> ut, vt;
+    for (int r = H.rtiles.node_tile_begin[b.t_node]; r < H.rtiles.node_tile_end[b.t_node]; r++) ut.push_back(r);
+    if (b.rank > 0) for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) vt.push_back(c);
+    int *d_ut = upload(ut), *d_vt = upload(vt);
+    int *d_rto = upload(H.rtiles.off), *d_rts = upload(H.rtiles.size), *d_cto = upload(H.ctiles.off), *d_cts = upload(H.ctiles.size);
+    std::vector<long long> t1(L.b_pbase.begin(), L.b_pbase.end()), t3(L.a_pbase.begin(), L.a_pbase.end());
+    long long *d_bp = upload(t1), *d_ap = upload(t3);
+    int *d_an = upload(L.a_nrows);
+    const int ncolsU = b.rank >= 0 ? b.rank : b.n;
+    void *d_outA = nullptr, *d_outB = nullptr;
+    HIP_OK(hipMalloc(&d_outA, (size_t)b.m * ncolsU * es));
+    a.item_tile = d_ut; a.tile_off = d_rto; a.tile_size = d_rts; a.tile_pbase = d_bp; a.panel = D->batches[b.batch].panelB;
+    if (H.is_complex) hipLaunchKernelGGL(unpack_u_kernel<double2>, dim3((unsigned)ut.size()), dim3(256), 0, D->stream, a, (double2 *)d_outA);
+    else hipLaunchKernelGGL(unpack_u_kernel<double>, dim3((unsigned)ut.size()), dim3(256), 0, D->stream, a, (double *)d_outA);
+    if (b.rank > 0) {
+        HIP_OK(hipMalloc(&d_outB, (size_t)b.n * b.rank * es));
+        a.item_tile = d_vt; a.tile_off = d_cto; a.tile_size = d_cts; a.tile_pbase = d_ap; a.tile_n = d_an; a.panel = D->batches[b.batch].panelA;
+        if (H.is_complex) hipLaunchKernelGGL(unpack_v_kernel<double2>, dim3((unsigned)vt.size()), dim3(256), 0, D->stream, a, (double2 *)d_outB);
+        else hipLaunchKernelGGL(unpack_v_kernel<double>, dim3((unsigned)vt.size()), dim3(256), 0, D->stream, a, (double *)d_outB);
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(D->stream));
+    HIP_OK(hipMemcpy(A, d_outA, (size_t)b.m * ncolsU * es, hipMemcpyDeviceToHost));
+    if (b.rank > 0) HIP_OK(hipMemcpy(Bout, d_outB, (size_t)b.n * b.rank * es, hipMemcpyDeviceToHost));
+    for (void *p : {(void *)d_b, (void *)d_ut, (void *)d_vt, (void *)d_rto, (void *)d_rts, (void *)d_cto, (void *)d_cts, (void *)d_bp, (void *)d_ap, (void *)d_an, d_outA, d_outB})
+        if (p) (void)hipFree(p);
+}
+
+} // namespace hm
+
+#include "device_build.inc"

@@ -1,0 +1,85 @@
+// device_internal.hpp -- structures shared by the .hip translation units (never seen by g++ files)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "hmatrix.hpp"
+
+namespace hm {
+
+#define HIP_OK(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) throw hm::Error(hm::strprintf("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call)); \
+    } while (0)
+
+// one column segment of a tile panel (device view); T elements are double (real) or double2 (complex)
+struct GSeg {
+    const void *panel;     // first element
+    const int *cidx;       // coefficient index (into W) of every column
+    int ncols;
+    int ld_full;           // leading dimension of full row chunks
+    int ld_last;           // leading dimension of the last (or only) row chunk
+    int pad_;
+    long long chunk_stride; // elements between consecutive row chunks
+};
+
+struct GTile {
+    long long seg_begin;
+    int nseg;
+    int nrows;
+    const int *omap;       // output index of row i is omap[i] when non-null ...
+    long long out_begin;   // ... and out_begin + i otherwise
+};
+
+struct DevBatch {
+    void *panelB = nullptr, *panelA = nullptr;
+    int *cidxB = nullptr, *oidxA = nullptr;
+    size_t bytes = 0;
+};
+
+// what table assembly / introspection needs to remember about a packed batch (host copies)
+struct BatchTables {
+    std::vector<int> b_ncols, a_nrows;
+    std::vector<int64_t> b_pbase, b_cbase, a_pbase, a_obase;
+    std::vector<BatchLayout::Reduce> reduces;
+};
+
+struct DeviceHMatrix {
+    int device = 0;
+    std::vector<BatchTables> tabs;
+    bool is_complex = false;
+    size_t esize = 8;
+    std::vector<DevBatch> batches;
+    GSeg *segs = nullptr;
+    GTile *tilesB_user = nullptr, *tilesB_cluster = nullptr, *tilesA = nullptr, *tilesA2 = nullptr;
+    int nB = 0, nA = 0, nA2 = 0;
+    int *perm_s = nullptr, *perm_t = nullptr, *iota = nullptr, *ones_idx = nullptr;
+    void *W = nullptr;
+    long long W_elems = 0;
+    void *x_tmp = nullptr, *y_tmp = nullptr;
+    int n_source = 0, n_target = 0, row_off = 0, row_size = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_us = -1;
+    size_t table_bytes = 0;
+    // cluster-ordered coordinates (SoA x|y|z) of a native generator, kept for dense evaluation / ACA
+    double *tcoord = nullptr, *scoord = nullptr;
+};
+
+// per-block device descriptor used by the pack / unpack / ACA kernels
+struct DevBlock {
+    long long tmp_u, tmp_v; // arena offsets (elements)
+    long long tpos;
+    long long v_obase;
+    int t_off, m, s_off, n;
+    int rank;               // -1 dense
+    int cap;
+    int ucol, vcol;
+    int v_ostride, v_tile0;
+    int status, pad_;
+};
+
+} // namespace hm

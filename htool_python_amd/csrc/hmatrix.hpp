@@ -1,0 +1,146 @@
+// hmatrix.hpp -- flattened H-matrix: host bookkeeping + handles to the HBM-resident panels.
+//
+// Data layout in HBM.  All leaves are contiguous index ranges in cluster
+// numbering, so the rows [row_off, row_off+row_size) and the source positions [0, n_source) are cut
+// into TILES (pieces of cluster-tree leaves, at most TM entries).  The panels of all leaves are
+// re-grouped per tile so that every kernel streams contiguous memory:
+//   phase B ("wide" tiles, one per row tile): the U rows of every low-rank leaf covering the tile
+//     and the rows of every dense leaf of the tile, concatenated column after column; column c has
+//     a coefficient index cidx[c] into the coefficient vector W;  y_tile = Panel * W[cidx].
+//   phase A ("tall" tiles, one per source tile): the V columns of every low-rank leaf covering the
+//     source tile: rows = (leaf, k) pairs, columns = source positions;  t = Panel * x_tile.
+//   phase A2 ("tall" tiles): sums the per-source-tile partials of leaves spanning several tiles.
+// W = [ x permuted (n_source) | 1.0 | R ] where R holds the t vectors and phase-A partials.
+// A panel with nrows x ncols entries is stored as row chunks of TM rows; chunk q is column-major
+// [col][ld_q] with ld_q = TM (full chunks) or the remainder rounded up to the vector width.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cluster.hpp"
+#include "common.hpp"
+
+namespace hm {
+
+// one leaf of the block cluster tree
+struct BlockRec {
+    int t_node, s_node;
+    int t_off, m, s_off, n;
+    int rank;  // -1 dense, >= 0 low rank
+    int cap;   // rank capacity reserved in the temporary arena (low rank only)
+    int batch; // which pack batch holds its panels
+    int64_t tmp_u, tmp_v; // element offsets in the temporary arena: U [k][i] (stride m) or D col-major; V [k][j] (stride n)
+    int ucol, vcol;       // first column in the phase-B tile panels / first row in the phase-A tile panels
+    int64_t tpos;         // index in W of t_b[0]
+    int64_t v_obase;      // phase-A output index of (k=0, first source tile)
+    int v_ostride;        // phase-A output stride between consecutive source tiles (0: single tile)
+    int status;           // device ACA status (0 ok, 1 not compressible, 2 capacity exceeded)
+};
+
+struct TileSet {
+    std::vector<int> off, size;         // tiles in increasing offset order
+    std::vector<int> node_tile_begin;   // per cluster node: first tile
+    std::vector<int> node_tile_end;     // per cluster node: one past last tile
+    std::vector<int> leaf_of_tile;      // cluster leaf node containing the tile
+    int count() const { return (int)off.size(); }
+};
+
+TileSet make_tiles(const ClusterTree &T, int root_node, int tile_max);
+
+// host description of what one pack batch needs (computed by layout.cpp, consumed by device.hip)
+struct BatchLayout {
+    int batch_id = 0;
+    std::vector<int64_t> blocks; // indices into HMatrix::blocks that belong to this batch (rank != 0)
+    // phase B: per row tile
+    std::vector<int> b_ncols;      // columns contributed by this batch
+    std::vector<int64_t> b_pbase;  // element offset of the tile's panel in panelB
+    std::vector<int64_t> b_cbase;  // offset of the tile's cidx in cidxB
+    int64_t panelB_elems = 0, cidxB_elems = 0;
+    // phase A: per source tile
+    std::vector<int> a_nrows;      // (leaf,k) rows contributed by this batch
+    std::vector<int64_t> a_pbase;  // element offset in panelA
+    std::vector<int64_t> a_obase;  // offset of the tile's output-index list in oidxA
+    int64_t panelA_elems = 0, oidxA_elems = 0;
+    // phase A2 tiles: (partial panel offset in W, ld, rows, cols, output base in W)
+    struct Reduce { int64_t w_panel; int ld; int nrows; int ncols; int64_t out_base; };
+    std::vector<Reduce> reduces;
+    // pack work items (block index into `blocks`, tile id)
+    std::vector<int> u_item_block, u_item_tile, v_item_block, v_item_tile;
+};
+
+struct DeviceHMatrix; // defined in device.hip
+
+struct BuildParams {
+    double epsilon = 1e-3, eta = 10;
+    char symmetry = 'N', uplo = 'N';
+    int reqrank = -1, min_target_depth = 0, min_source_depth = 0, block_tree_consistency = 1;
+    int (*compress)(void *, int, int, const int *, const int *, double, const void **, const void **, int *) = nullptr;
+    void *compress_ctx = nullptr;
+    void (*dense_blocks)(void *, int, const int *, const int *, const int *, const int *, void **) = nullptr;
+    void *dense_blocks_ctx = nullptr;
+};
+
+struct Generator {
+    bool is_complex = false;
+    bool native = false;
+    // callback flavour
+    void (*fn)(void *, int, int, const int *, const int *, void *) = nullptr;
+    void *ctx = nullptr;
+    // native flavour
+    int kind = 0, dim = 3;
+    double param = 0;
+    std::vector<double> tpts, spts; // point-major copies, user numbering
+    int n_target = 0, n_source = 0;
+};
+
+struct HMatrix {
+    const ClusterTree *tc = nullptr, *sc = nullptr;
+    int t_root = 0;                 // target node the matrix was built on (root or a partition)
+    int row_off = 0, row_size = 0;  // rows covered, cluster numbering
+    bool is_complex = false;
+    BuildParams params;
+    int tile_max = 128;
+    TileSet rtiles, ctiles;
+    std::vector<BlockRec> blocks;
+    int64_t r_elems = 0;            // size of region R of W
+    double build_seconds = 0;
+    int n_batches = 0;
+    DeviceHMatrix *dev = nullptr;   // HBM-resident part (device.hip)
+    ~HMatrix();
+};
+
+// ---- block tree (blocktree.cpp) ----
+void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int sym_partition,
+                      std::vector<BlockRec> &adm, std::vector<BlockRec> &dns);
+// sub-blocks of an admissible block whose compression failed (re-visit ignoring its own admissibility)
+void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, const BlockRec &b,
+                        std::vector<BlockRec> &adm, std::vector<BlockRec> &dns);
+
+// ---- layout (layout.cpp) ----
+// assigns ucol/vcol/tpos/... of the given blocks (one batch) and fills the BatchLayout.
+void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, int vec_rows, BatchLayout &L);
+
+// ---- host build for callback generators (build_host.cpp) ----
+// runs ACA / the custom compressor / the dense fill on the calling thread; fills a host arena laid out
+// like the device temporary arena and sets rank/tmp_u/tmp_v of every block.
+template <typename T>
+void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena);
+
+// ---- device side (device.hip) ----
+int device_count();
+void device_select(int dev);
+std::string device_name();
+// whole build for a callback generator: upload the host arena, pack, assemble the product tables
+void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems);
+// whole build for a native generator: device ACA + dense evaluation + pack
+void device_build_native(HMatrix &H, const Generator &g);
+void device_matvec_host(const HMatrix &H, const void *x, void *y);                                    // user numbering
+void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream);
+void device_clone(const HMatrix &src, HMatrix &dst);
+void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *B);
+int64_t device_resident_bytes(const HMatrix &H);
+double device_last_product_us(const HMatrix &H);
+void device_free(DeviceHMatrix *d);
+
+} // namespace hm

@@ -1,0 +1,131 @@
+// layout.cpp -- where every leaf's panels go in the tile-major HBM layout (hmatrix.hpp header).
+//
+// Columns of a row tile are ordered top-down through the target cluster tree: first the leaves
+// attached to the tile's shallowest ancestor, ..., last those attached to the cluster leaf itself
+// (low-rank before dense).  With that order the first column of a leaf (ucol) is the same in every
+// tile the leaf covers, so one (ucol, vcol) pair per leaf describes the whole scatter.
+#include <algorithm>
+
+#include "hmatrix.hpp"
+
+namespace hm {
+
+static inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, int vec_rows, BatchLayout &L) {
+    const ClusterTree &T = *H.tc, &S = *H.sc;
+    const int TM = H.tile_max;
+    const int nt = T.node_count(), ns = S.node_count();
+    L.blocks = batch_blocks;
+
+    // ---- target side: columns per node, low-rank first then dense
+    std::vector<int> Klr(nt, 0), Kdn(nt, 0);
+    for (int64_t bi : batch_blocks) {
+        BlockRec &b = H.blocks[bi];
+        if (b.rank >= 0) { b.ucol = Klr[b.t_node]; Klr[b.t_node] += b.rank; }
+    }
+    for (int64_t bi : batch_blocks) {
+        BlockRec &b = H.blocks[bi];
+        if (b.rank < 0) { b.ucol = Klr[b.t_node] + Kdn[b.t_node]; Kdn[b.t_node] += b.n; }
+    }
+    std::vector<int> tbase(nt, 0);
+    for (int id = 0; id < nt; id++) { // parents precede children in the node table
+        int p = T.parent[id];
+        if (id != H.t_root && p >= 0) tbase[id] = tbase[p] + Klr[p] + Kdn[p];
+    }
+    tbase[H.t_root] = 0;
+    for (int64_t bi : batch_blocks) H.blocks[bi].ucol += tbase[H.blocks[bi].t_node];
+
+    const int nrt = H.rtiles.count();
+    L.b_ncols.assign(nrt, 0);
+    L.b_pbase.assign(nrt, 0);
+    L.b_cbase.assign(nrt, 0);
+    int64_t pb = 0, cb = 0;
+    for (int r = 0; r < nrt; r++) {
+        int leaf = H.rtiles.leaf_of_tile[r];
+        int nc = tbase[leaf] + Klr[leaf] + Kdn[leaf];
+        L.b_ncols[r] = nc;
+        L.b_pbase[r] = pb;
+        L.b_cbase[r] = cb;
+        pb += (int64_t)nc * round_up(H.rtiles.size[r], vec_rows);
+        cb += nc;
+    }
+    L.panelB_elems = pb;
+    L.cidxB_elems = cb;
+
+    // ---- source side: rows (leaf,k) per node, low-rank leaves only
+    std::vector<int> Ks(ns, 0);
+    std::vector<int> cs_of(batch_blocks.size(), 0);
+    for (size_t q = 0; q < batch_blocks.size(); q++) {
+        BlockRec &b = H.blocks[batch_blocks[q]];
+        if (b.rank >= 0) { cs_of[q] = Ks[b.s_node]; b.vcol = Ks[b.s_node]; Ks[b.s_node] += b.rank; }
+    }
+    std::vector<int> sbase(ns, 0);
+    for (int id = 1; id < ns; id++) sbase[id] = sbase[S.parent[id]] + Ks[S.parent[id]];
+    for (int64_t bi : batch_blocks) if (H.blocks[bi].rank >= 0) H.blocks[bi].vcol += sbase[H.blocks[bi].s_node];
+
+    const int nct = H.ctiles.count();
+    L.a_nrows.assign(nct, 0);
+    L.a_pbase.assign(nct, 0);
+    L.a_obase.assign(nct, 0);
+    int64_t pa = 0, oa = 0;
+    for (int c = 0; c < nct; c++) {
+        int leaf = H.ctiles.leaf_of_tile[c];
+        int nr = sbase[leaf] + Ks[leaf];
+        L.a_nrows[c] = nr;
+        L.a_pbase[c] = pa;
+        L.a_obase[c] = oa;
+        if (nr > 0) {
+            int nq = (nr + TM - 1) / TM;
+            int padded = TM * (nq - 1) + round_up(nr - TM * (nq - 1), vec_rows);
+            pa += (int64_t)padded * H.ctiles.size[c];
+        }
+        oa += nr;
+    }
+    L.panelA_elems = pa;
+    L.oidxA_elems = oa;
+
+    // ---- region R of W: t vectors, and partial panels for source nodes spanning several tiles
+    const int64_t r_start = round_up(S.n_points + 1, 2); // W index of R[0]
+    std::vector<int64_t> tb(ns, -1), pbse(ns, -1);
+    std::vector<int> ldp(ns, 0);
+    int64_t cur = H.r_elems;
+    for (int id = 0; id < ns; id++) {
+        if (Ks[id] == 0) continue;
+        tb[id] = cur;
+        cur += Ks[id];
+        int P = H.ctiles.node_tile_end[id] - H.ctiles.node_tile_begin[id];
+        if (P > 1) {
+            cur = (cur + 1) / 2 * 2;
+            ldp[id] = round_up(Ks[id], vec_rows);
+            pbse[id] = cur;
+            cur += (int64_t)P * ldp[id];
+            L.reduces.push_back({r_start + pbse[id], ldp[id], Ks[id], P, r_start + tb[id]});
+        }
+    }
+    H.r_elems = cur;
+    for (size_t q = 0; q < batch_blocks.size(); q++) {
+        BlockRec &b = H.blocks[batch_blocks[q]];
+        if (b.rank < 0) continue;
+        int id = b.s_node;
+        b.tpos = r_start + tb[id] + cs_of[q];
+        if (pbse[id] >= 0) { b.v_obase = r_start + pbse[id] + cs_of[q]; b.v_ostride = ldp[id]; }
+        else { b.v_obase = b.tpos; b.v_ostride = 0; }
+    }
+
+    // ---- pack work items
+    for (size_t q = 0; q < batch_blocks.size(); q++) {
+        const BlockRec &b = H.blocks[batch_blocks[q]];
+        for (int r = H.rtiles.node_tile_begin[b.t_node]; r < H.rtiles.node_tile_end[b.t_node]; r++) {
+            L.u_item_block.push_back((int)q);
+            L.u_item_tile.push_back(r);
+        }
+        if (b.rank >= 0)
+            for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) {
+                L.v_item_block.push_back((int)q);
+                L.v_item_tile.push_back(c);
+            }
+    }
+}
+
+} // namespace hm

@@ -1,0 +1,561 @@
+// pyhtool.cpp -- thin pybind11 module "Htool" over the C ABI of libhtool_mi355x.so.
+//
+// Mirrors the Python surface the reference registers in src/htool/main.cpp:40-112 for the H-matrix
+// build + product path (class names, argument names, defaults, error messages); every method only
+// converts arguments and forwards to include/htool_mi355x.h.  No arithmetic happens here.
+#include <pybind11/functional.h>
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <complex>
+#include <map>
+#include <memory>
+#include <optional>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/htool_mi355x.h"
+
+namespace py = pybind11;
+using namespace pybind11::literals;
+
+static void check(int rc) {
+    if (rc != 0) throw std::runtime_error(htool_last_error());
+}
+
+// ---- logging: C sink -> logging.getLogger("Htool") (src/htool/misc/logger.hpp:13-33) ------------
+static void python_log_sink(int level, const char *message) {
+    py::gil_scoped_acquire gil;
+    py::object logger = py::module::import("logging").attr("getLogger")("Htool");
+    switch (level) {
+    case 0: logger.attr("critical")(message); break;
+    case 1: logger.attr("error")(message); break;
+    case 2: logger.attr("warning")(message); break;
+    case 3: logger.attr("debug")(message); break;
+    default: logger.attr("info")(message); break;
+    }
+}
+
+// ---- clusters -------------------------------------------------------------------------------------
+struct ClusterRoot {
+    htool_cluster *root = nullptr;
+    ~ClusterRoot() { htool_cluster_destroy(root); }
+};
+struct PyCluster {
+    std::shared_ptr<ClusterRoot> owner;
+    const htool_cluster *node = nullptr;
+};
+
+struct PyPartitioning {
+    int strategy = HTOOL_PCA_REGULAR;
+    virtual ~PyPartitioning() = default;
+};
+template <int S>
+struct PyPartitioningT : PyPartitioning {
+    PyPartitioningT() { strategy = S; }
+};
+
+struct PyClusterTreeBuilder {
+    int max_leaf = 10;
+    int strategy = HTOOL_PCA_REGULAR;
+    typedef py::array_t<double, py::array::f_style | py::array::forcecast> coords_t;
+    typedef py::array_t<int, py::array::f_style | py::array::forcecast> part_t;
+
+    PyCluster create(coords_t coordinates, int number_of_children, int size_of_partition, const int *partition, bool local,
+                     std::optional<coords_t> radii, std::optional<coords_t> weights) {
+        if (coordinates.ndim() != 2) throw std::runtime_error("coordinates must be a (dimension, number_of_points) array");
+        auto owner = std::make_shared<ClusterRoot>();
+        // a (d, N) Fortran-ordered array is point-major in memory (cluster_tree_builder.hpp:19-23)
+        check(htool_cluster_create(coordinates.data(), (int)coordinates.shape(1), (int)coordinates.shape(0), radii ? radii->data() : nullptr,
+                                   weights ? weights->data() : nullptr, number_of_children, size_of_partition, partition, local ? 1 : 0, max_leaf, strategy,
+                                   &owner->root));
+        return PyCluster{owner, owner->root};
+    }
+};
+
+// ---- generators -----------------------------------------------------------------------------------
+template <typename T>
+struct PyIGenerator {
+    virtual ~PyIGenerator() = default;
+    htool_generator *handle = nullptr; // created lazily
+    virtual htool_generator *get() = 0;
+};
+
+template <typename T>
+struct PyVirtualGenerator : PyIGenerator<T> {
+    PyVirtualGenerator() {}
+    PyVirtualGenerator(const py::array_t<int> &, const py::array_t<int> &) {}
+    ~PyVirtualGenerator() override { if (this->handle) htool_generator_destroy(this->handle); }
+    virtual void build_submatrix(const py::array_t<int> &J, const py::array_t<int> &K, py::array_t<T, py::array::f_style> &mat) const = 0;
+
+    // C callback -> Python build_submatrix; numpy views over the library's buffers, no copies
+    // (src/htool/hmatrix/interfaces/virtual_generator.hpp:16-25)
+    static void trampoline(void *ctx, int M, int N, const int *rows, const int *cols, void *out) {
+        if ((long)M * N <= 0) return;
+        auto *self = static_cast<PyVirtualGenerator<T> *>(ctx);
+        py::array_t<T, py::array::f_style> mat(std::array<py::ssize_t, 2>{M, N}, (T *)out, py::capsule(out, [](void *) {}));
+        py::array_t<int> py_rows(std::array<py::ssize_t, 1>{M}, rows, py::capsule(rows, [](void *) {}));
+        py::array_t<int> py_cols(std::array<py::ssize_t, 1>{N}, cols, py::capsule(cols, [](void *) {}));
+        self->build_submatrix(py_rows, py_cols, mat);
+    }
+    htool_generator *get() override {
+        if (!this->handle) check(htool_generator_create_callback(std::is_same<T, double>::value ? 0 : 1, &trampoline, this, &this->handle));
+        return this->handle;
+    }
+};
+
+template <typename T>
+struct PyVirtualGeneratorTrampoline : PyVirtualGenerator<T> {
+    using PyVirtualGenerator<T>::PyVirtualGenerator;
+    void build_submatrix(const py::array_t<int> &J, const py::array_t<int> &K, py::array_t<T, py::array::f_style> &mat) const override {
+        PYBIND11_OVERRIDE_PURE(void, PyVirtualGenerator<T>, build_submatrix, J, K, mat);
+    }
+};
+
+// native generator: kernel evaluated on the device (extension of the reference API; the reference only
+// has callback generators).  kind: "inv_delta" | "laplace" | "helmholtz"
+template <typename T>
+struct PyNativeGenerator : PyIGenerator<T> {
+    typedef py::array_t<double, py::array::f_style | py::array::forcecast> coords_t;
+    PyNativeGenerator(const std::string &kind, coords_t target_points, coords_t source_points, double param) {
+        int k = kind == "inv_delta" ? HTOOL_KERNEL_INV_DELTA : kind == "laplace" ? HTOOL_KERNEL_LAPLACE : kind == "helmholtz" ? HTOOL_KERNEL_HELMHOLTZ : -1;
+        if (k < 0) throw std::runtime_error("unknown kernel kind '" + kind + "'");
+        if ((k == HTOOL_KERNEL_HELMHOLTZ) != !std::is_same<T, double>::value) throw std::runtime_error("kernel kind does not match the coefficient type of this generator class");
+        if (target_points.ndim() != 2 || source_points.ndim() != 2 || target_points.shape(0) != source_points.shape(0)) throw std::runtime_error("points must be (dimension, n) arrays");
+        check(htool_generator_create_native(k, (int)target_points.shape(0), target_points.data(), (int)target_points.shape(1), source_points.data(),
+                                            (int)source_points.shape(1), param, &this->handle));
+    }
+    ~PyNativeGenerator() override { if (this->handle) htool_generator_destroy(this->handle); }
+    htool_generator *get() override { return this->handle; }
+};
+
+// ---- custom low-rank generator (virtual_low_rank_generator.hpp:17-92) ------------------------------
+template <typename T>
+struct PyVirtualLowRankGenerator {
+    typedef typename std::conditional<std::is_same<T, double>::value, double, double>::type real_t;
+    mutable std::vector<py::array_t<T, py::array::f_style>> mats_U, mats_V; // owned by Python
+    bool allow_copy = true;
+    mutable std::vector<T> scratch_U, scratch_V;
+    explicit PyVirtualLowRankGenerator(bool allow_copy_ = true) : allow_copy(allow_copy_) {}
+    virtual ~PyVirtualLowRankGenerator() = default;
+    virtual bool build_low_rank_approximation(const py::array_t<int, py::array::f_style> &rows, const py::array_t<int, py::array::f_style> &cols, double epsilon) const = 0;
+    void set_U(py::array_t<T, py::array::f_style> U0) { mats_U.push_back(U0); }
+    void set_V(py::array_t<T, py::array::f_style> V0) { mats_V.push_back(V0); }
+    void clear_data() {
+        mats_U.clear();
+        mats_V.clear();
+    }
+    static int trampoline(void *ctx, int M, int N, const int *rows, const int *cols, double epsilon, const void **U, const void **V, int *rank) {
+        auto *self = static_cast<PyVirtualLowRankGenerator<T> *>(ctx);
+        py::array_t<int, py::array::f_style> py_rows(std::array<py::ssize_t, 1>{M}, rows, py::capsule(rows, [](void *) {}));
+        py::array_t<int, py::array::f_style> py_cols(std::array<py::ssize_t, 1>{N}, cols, py::capsule(cols, [](void *) {}));
+        size_t before_u = self->mats_U.size(), before_v = self->mats_V.size();
+        bool ok = self->build_low_rank_approximation(py_rows, py_cols, epsilon);
+        if (!ok) return 0;
+        if (self->mats_U.size() <= before_u || self->mats_V.size() <= before_v) throw std::runtime_error("build_low_rank_approximation returned True without calling set_U and set_V");
+        auto &Um = self->mats_U.back();
+        auto &Vm = self->mats_V.back();
+        if (Um.ndim() != 2 || Vm.ndim() != 2 || Um.shape(0) != M || Vm.shape(1) != N || Um.shape(1) != Vm.shape(0)) throw std::runtime_error("set_U/set_V: expected U (M x r) and V (r x N)");
+        *rank = (int)Um.shape(1);
+        // the panels live in HBM afterwards, so the library always copies; with allow_copy the Python
+        // references are dropped right away (virtual_low_rank_generator.hpp:33-38), otherwise they stay
+        // until clear_data() as in the reference (:39-42)
+        *U = Um.data();
+        *V = Vm.data();
+        if (self->allow_copy) {
+            self->scratch_U.assign(Um.data(), Um.data() + Um.size());
+            self->scratch_V.assign(Vm.data(), Vm.data() + Vm.size());
+            *U = self->scratch_U.data();
+            *V = self->scratch_V.data();
+            self->mats_U.pop_back();
+            self->mats_V.pop_back();
+        }
+        return 1;
+    }
+};
+template <typename T>
+struct PyVirtualLowRankGeneratorTrampoline : PyVirtualLowRankGenerator<T> {
+    using PyVirtualLowRankGenerator<T>::PyVirtualLowRankGenerator;
+    bool build_low_rank_approximation(const py::array_t<int, py::array::f_style> &rows, const py::array_t<int, py::array::f_style> &cols, double epsilon) const override {
+        PYBIND11_OVERRIDE_PURE(bool, PyVirtualLowRankGenerator<T>, build_low_rank_approximation, rows, cols, epsilon);
+    }
+};
+
+// ---- custom dense blocks generator (virtual_dense_blocks_generator.hpp:10-69) -----------------------
+template <typename T>
+struct PyVirtualDenseBlocksGenerator {
+    PyCluster target, source;
+    PyVirtualDenseBlocksGenerator(const PyCluster &t, const PyCluster &s) : target(t), source(s) {}
+    virtual ~PyVirtualDenseBlocksGenerator() = default;
+    virtual void build_dense_blocks(const std::vector<py::array_t<int, py::array::f_style>> &rows, const std::vector<py::array_t<int, py::array::f_style>> &cols,
+                                    std::vector<py::array_t<T, py::array::f_style>> &blocks) const = 0;
+    static void trampoline(void *ctx, int nb, const int *M, const int *N, const int *row_offsets, const int *col_offsets, void **ptrs) {
+        auto *self = static_cast<PyVirtualDenseBlocksGenerator<T> *>(ctx);
+        int nt = 0, ns = 0;
+        const int *pt = htool_cluster_permutation(self->target.node, &nt), *ps = htool_cluster_permutation(self->source.node, &ns);
+        std::vector<py::array_t<T, py::array::f_style>> vec_ptr;
+        std::vector<py::array_t<int, py::array::f_style>> rows_ptr, cols_ptr;
+        for (int i = 0; i < nb; i++) {
+            rows_ptr.emplace_back(std::array<py::ssize_t, 1>{M[i]}, pt + row_offsets[i], py::capsule(pt, [](void *) {}));
+            cols_ptr.emplace_back(std::array<py::ssize_t, 1>{N[i]}, ps + col_offsets[i], py::capsule(ps, [](void *) {}));
+            vec_ptr.emplace_back(std::array<py::ssize_t, 2>{M[i], N[i]}, (T *)ptrs[i], py::capsule(ptrs[i], [](void *) {}));
+        }
+        self->build_dense_blocks(rows_ptr, cols_ptr, vec_ptr);
+    }
+};
+template <typename T>
+struct PyVirtualDenseBlocksGeneratorTrampoline : PyVirtualDenseBlocksGenerator<T> {
+    using PyVirtualDenseBlocksGenerator<T>::PyVirtualDenseBlocksGenerator;
+    void build_dense_blocks(const std::vector<py::array_t<int, py::array::f_style>> &rows, const std::vector<py::array_t<int, py::array::f_style>> &cols,
+                            std::vector<py::array_t<T, py::array::f_style>> &blocks) const override {
+        PYBIND11_OVERRIDE_PURE(void, PyVirtualDenseBlocksGenerator<T>, build_dense_blocks, rows, cols, blocks);
+    }
+};
+
+// ---- H-matrix -------------------------------------------------------------------------------------
+static std::map<std::string, std::string> parse_info(const htool_hmatrix *h, int which) {
+    int need = htool_hmatrix_info(h, which, nullptr, 0);
+    std::string buf((size_t)need, '\0');
+    htool_hmatrix_info(h, which, &buf[0], need);
+    std::map<std::string, std::string> out;
+    std::istringstream in(buf.c_str());
+    std::string line;
+    while (std::getline(in, line)) {
+        auto eq = line.find('=');
+        if (eq != std::string::npos) out[line.substr(0, eq)] = line.substr(eq + 1);
+    }
+    return out;
+}
+
+template <typename T>
+struct PyHMatrix {
+    htool_hmatrix *h = nullptr;
+    bool owned = true;
+    PyCluster target, source; // keep the cluster trees alive (the reference stores references)
+    PyHMatrix() {}
+    PyHMatrix(const PyHMatrix &) = delete;
+    PyHMatrix(PyHMatrix &&o) noexcept : h(o.h), owned(o.owned), target(o.target), source(o.source) { o.h = nullptr; }
+    ~PyHMatrix() { if (h && owned) htool_hmatrix_destroy(h); }
+
+    py::array_t<T, py::array::f_style> mul(const py::array_t<T, py::array::f_style> &input) const {
+        if (input.ndim() != 1) throw std::runtime_error("Wrong dimension for HMatrix-vector product");
+        if (input.shape(0) != htool_hmatrix_nb_cols(h)) throw std::runtime_error("Wrong size for HMatrix-vector product");
+        py::array_t<T, py::array::f_style> result(htool_hmatrix_nb_rows(h));
+        std::fill_n(result.mutable_data(), result.size(), T(0));
+        T one(1), zero(0);
+        check(htool_hmatrix_matvec(h, 'N', &one, input.data(), &zero, result.mutable_data()));
+        return result;
+    }
+    py::array_t<T, py::array::f_style> matmul(const py::array_t<T, py::array::f_style> &input) const {
+        if (input.ndim() != 2) throw std::runtime_error("Wrong dimension for HMatrix-matrix product");
+        if (input.shape(0) != htool_hmatrix_nb_cols(h)) throw std::runtime_error("Wrong size for HMatrix-matrix product");
+        py::array_t<T, py::array::f_style> result({(py::ssize_t)htool_hmatrix_nb_rows(h), input.shape(1)});
+        std::fill_n(result.mutable_data(), result.size(), T(0));
+        T one(1), zero(0);
+        check(htool_hmatrix_matmat(h, 'N', &one, input.data(), (int)input.shape(1), &zero, result.mutable_data()));
+        return result;
+    }
+    py::array_t<T, py::array::f_style> dense(bool user) const {
+        py::array_t<T, py::array::f_style> out({(py::ssize_t)htool_hmatrix_nb_rows(h), (py::ssize_t)htool_hmatrix_nb_cols(h)});
+        std::fill_n(out.mutable_data(), out.size(), T(0));
+        check(htool_hmatrix_to_dense(h, out.mutable_data(), user ? 1 : 0));
+        return out;
+    }
+};
+
+template <typename T>
+struct PyHMatrixTreeBuilder {
+    htool_build_params p;
+    std::shared_ptr<PyVirtualLowRankGenerator<T>> low_rank;
+    std::shared_ptr<PyVirtualDenseBlocksGenerator<T>> dense_blocks;
+    PyHMatrixTreeBuilder(double epsilon, double eta, char symmetry, char UPLO, int reqrank, std::shared_ptr<PyVirtualLowRankGenerator<T>> lr) : low_rank(lr) {
+        htool_build_params_default(&p);
+        p.epsilon = epsilon;
+        p.eta = eta;
+        p.symmetry = symmetry;
+        p.uplo = UPLO;
+        p.reqrank = reqrank;
+    }
+    htool_build_params resolved() const {
+        htool_build_params q = p;
+        if (low_rank) { q.compress = &PyVirtualLowRankGenerator<T>::trampoline; q.compress_ctx = low_rank.get(); }
+        if (dense_blocks) { q.dense_blocks = &PyVirtualDenseBlocksGenerator<T>::trampoline; q.dense_blocks_ctx = dense_blocks.get(); }
+        return q;
+    }
+    PyHMatrix<T> build(PyIGenerator<T> &generator, const PyCluster &target, const PyCluster &source, int target_partition_number, int partition_number_for_symmetry) const {
+        PyHMatrix<T> H;
+        H.target = target;
+        H.source = source;
+        htool_build_params q = resolved();
+        check(htool_hmatrix_build(generator.get(), target.owner->root, source.owner->root, &q, target_partition_number, partition_number_for_symmetry, &H.h));
+        return H;
+    }
+};
+
+// ---- communicator adapter (stand-in for the mpi4py caster of src/htool/misc/wrapper_mpi.hpp:28-55) ----
+struct PyComm {
+    py::object obj;
+    htool_comm c;
+    static int allgatherv(void *ctx, const void *send, int64_t send_bytes, void *recv, const int64_t *recv_bytes, const int64_t *displs) {
+        PyComm *self = static_cast<PyComm *>(ctx);
+        try {
+            int64_t total = 0;
+            std::vector<int64_t> cnt(self->c.size), dsp(self->c.size);
+            for (int p = 0; p < self->c.size; p++) { cnt[p] = recv_bytes[p]; dsp[p] = displs[p]; total = std::max(total, displs[p] + recv_bytes[p]); }
+            py::array_t<unsigned char> s(std::array<py::ssize_t, 1>{(py::ssize_t)send_bytes}, (const unsigned char *)send, py::capsule(send, [](void *) {}));
+            py::array_t<unsigned char> r(std::array<py::ssize_t, 1>{(py::ssize_t)total}, (unsigned char *)recv, py::capsule(recv, [](void *) {}));
+            self->obj.attr("_htool_allgatherv")(s, r, cnt, dsp);
+        } catch (py::error_already_set &e) {
+            e.restore();
+            return 1;
+        }
+        return 0;
+    }
+    explicit PyComm(py::object o) : obj(o) {
+        c.rank = py::cast<int>(o.attr("Get_rank")());
+        c.size = py::cast<int>(o.attr("Get_size")());
+        c.ctx = this;
+        c.allgatherv = &allgatherv;
+        if (c.size > 1 && !py::hasattr(o, "_htool_allgatherv")) throw std::runtime_error("communicator object must provide _htool_allgatherv (use the mpi4py shim shipped with this package)");
+    }
+};
+
+template <typename T>
+struct PyDistributedOperator {
+    htool_distributed *d = nullptr;
+    std::shared_ptr<PyComm> comm;
+    py::array_t<T, py::array::f_style> mul(const py::array_t<T, py::array::f_style> &input) const {
+        int rows, cols;
+        htool_distributed_shape(d, &rows, &cols);
+        if (input.ndim() != 1) throw std::runtime_error("Wrong dimension for DistributedOperator-vector product");
+        if (input.shape(0) != cols) throw std::runtime_error("Wrong size for DistributedOperator-vector product");
+        py::array_t<T, py::array::f_style> result(std::array<py::ssize_t, 1>{rows});
+        std::fill_n(result.mutable_data(), rows, T(0));
+        check(htool_distributed_matvec(d, input.data(), result.mutable_data()));
+        return result;
+    }
+    py::array_t<T, py::array::f_style> matmul(py::array_t<T, py::array::f_style> input) const {
+        int rows, cols;
+        htool_distributed_shape(d, &rows, &cols);
+        if (input.ndim() != 2) throw std::runtime_error("Wrong dimension for HMatrix-matrix product");
+        if (input.shape(0) != cols) throw std::runtime_error("Wrong size for HMatrix-matrix product");
+        int mu = (int)input.shape(1);
+        py::array_t<T, py::array::f_style> result(std::array<py::ssize_t, 2>{rows, mu});
+        std::fill_n(result.mutable_data(), (size_t)rows * mu, T(0));
+        check(htool_distributed_matmat(d, input.data(), mu, result.mutable_data()));
+        return result;
+    }
+};
+
+template <typename T>
+struct PyDefaultApproximationBuilder {
+    htool_distributed *d = nullptr;
+    std::shared_ptr<PyComm> comm;
+    PyCluster target, source;
+    PyDistributedOperator<T> op;
+    PyHMatrix<T> hmat;
+    PyDefaultApproximationBuilder(PyIGenerator<T> &generator, const PyCluster &t, const PyCluster &s, const PyHMatrixTreeBuilder<T> &builder, py::object comm_obj)
+        : comm(std::make_shared<PyComm>(comm_obj)), target(t), source(s) {
+        htool_build_params q = builder.resolved();
+        check(htool_distributed_create_default(generator.get(), t.owner->root, s.owner->root, &q, &comm->c, &d));
+        op.d = d;
+        op.comm = comm;
+        hmat.h = htool_distributed_hmatrix(d);
+        hmat.owned = false;
+        hmat.target = t;
+        hmat.source = s;
+    }
+    ~PyDefaultApproximationBuilder() { htool_distributed_destroy(d); }
+};
+
+// ---- module ---------------------------------------------------------------------------------------
+template <typename T>
+static void declare_coefficient_classes(py::module &m, const std::string &prefix, const std::string &igenerator_name, const std::string &virtual_generator_name,
+                                        const std::string &low_rank_generator_name, const std::string &native_name) {
+    // generators (main.cpp:63,93)
+    py::class_<PyIGenerator<T>>(m, igenerator_name.c_str());
+    py::class_<PyVirtualGenerator<T>, PyIGenerator<T>, PyVirtualGeneratorTrampoline<T>>(m, virtual_generator_name.c_str())
+        .def(py::init<>())
+        .def(py::init<const py::array_t<int> &, const py::array_t<int> &>())
+        .def("build_submatrix", &PyVirtualGenerator<T>::build_submatrix);
+    py::class_<PyNativeGenerator<T>, PyIGenerator<T>>(m, native_name.c_str())
+        .def(py::init<const std::string &, typename PyNativeGenerator<T>::coords_t, typename PyNativeGenerator<T>::coords_t, double>(), "kind"_a, "target_points"_a,
+             "source_points"_a, "param"_a = 0.0);
+
+    // LowRankMatrix (hmatrix/lrmat.hpp:15-17): introspection record
+    struct LowRank { int m, n, r; };
+    py::class_<LowRank>(m, (prefix + "LowRankMatrix").c_str())
+        .def("nb_rows", [](const LowRank &l) { return l.m; })
+        .def("nb_cols", [](const LowRank &l) { return l.n; })
+        .def("rank", [](const LowRank &l) { return l.r; });
+
+    // custom hooks (main.cpp:66-67,95-96)
+    py::class_<PyVirtualLowRankGenerator<T>, std::shared_ptr<PyVirtualLowRankGenerator<T>>, PyVirtualLowRankGeneratorTrampoline<T>>(m, low_rank_generator_name.c_str())
+        .def(py::init<bool>(), "allow_copy"_a = true)
+        .def("build_low_rank_approximation", &PyVirtualLowRankGenerator<T>::build_low_rank_approximation)
+        .def("set_U", &PyVirtualLowRankGenerator<T>::set_U)
+        .def("set_V", &PyVirtualLowRankGenerator<T>::set_V)
+        .def("clear_data", &PyVirtualLowRankGenerator<T>::clear_data);
+    py::class_<PyVirtualDenseBlocksGenerator<T>, std::shared_ptr<PyVirtualDenseBlocksGenerator<T>>, PyVirtualDenseBlocksGeneratorTrampoline<T>>(
+        m, (prefix + "VirtualDenseBlocksGenerator").c_str())
+        .def(py::init<const PyCluster &, const PyCluster &>())
+        .def("build_dense_blocks", &PyVirtualDenseBlocksGenerator<T>::build_dense_blocks);
+
+    // HMatrix (hmatrix/hmatrix.hpp:27-138)
+    typedef PyHMatrix<T> H;
+    py::class_<H>(m, (prefix + "HMatrix").c_str())
+        .def_property_readonly("shape", [](const H &s) { return std::pair<int, int>(htool_hmatrix_nb_rows(s.h), htool_hmatrix_nb_cols(s.h)); })
+        .def("to_dense", [](const H &s) { return s.dense(false); })
+        .def("to_dense_in_user_numbering", [](const H &s) { return s.dense(true); })
+        .def("__deepcopy__", [](const H &s, py::dict) {
+                H c;
+                c.target = s.target;
+                c.source = s.source;
+                check(htool_hmatrix_clone(s.h, &c.h));
+                return c;
+            }, "memo"_a)
+        .def("get_tree_parameters", [](const H &s) { return parse_info(s.h, 0); })
+        .def("get_local_information", [](const H &s) { return parse_info(s.h, 1); })
+        .def("get_distributed_information", [](const H &s, py::object) { return parse_info(s.h, 1); })
+        .def("get_target_cluster", [](const H &s) { return PyCluster{s.target.owner, htool_hmatrix_target_cluster(s.h)}; })
+        .def("get_source_cluster", [](const H &s) { return PyCluster{s.source.owner, htool_hmatrix_source_cluster(s.h)}; })
+        .def("lu_factorization", [](H &) { throw std::runtime_error("H-LU factorization is outside the MI355X hot path (build + product); not implemented"); })
+        .def("cholesky_factorization", [](H &, char) { throw std::runtime_error("H-Cholesky factorization is outside the MI355X hot path (build + product); not implemented"); })
+        .def("lu_solve", [](const H &, char, py::object) -> py::object { throw std::runtime_error("H-LU solve is outside the MI355X hot path (build + product); not implemented"); })
+        .def("cholesky_solve", [](const H &, char, py::object) -> py::object { throw std::runtime_error("H-Cholesky solve is outside the MI355X hot path (build + product); not implemented"); })
+        .def("__mul__", &H::mul, "in"_a)
+        .def("__matmul__", &H::matmul, "in"_a)
+        // extensions used by tests / bench: flattened leaf table, leaf panels, statistics
+        .def("leaves", [](const H &s) {
+                int64_t n = htool_hmatrix_leaf_count(s.h);
+                py::array_t<int> out({(py::ssize_t)n, (py::ssize_t)5});
+                htool_hmatrix_leaves(s.h, out.mutable_data());
+                return out;
+            })
+        .def("leaf_panels", [](const H &s, int64_t i) -> py::object {
+                int64_t n = htool_hmatrix_leaf_count(s.h);
+                if (i < 0 || i >= n) throw std::runtime_error("leaf index out of range");
+                std::vector<int> all((size_t)n * 5);
+                htool_hmatrix_leaves(s.h, all.data());
+                int mm = all[5 * i + 1], nn = all[5 * i + 3], r = all[5 * i + 4];
+                if (r < 0) {
+                    py::array_t<T, py::array::f_style> A({(py::ssize_t)mm, (py::ssize_t)nn});
+                    check(htool_hmatrix_leaf_panels(s.h, i, A.mutable_data(), nullptr));
+                    return py::make_tuple(A, py::none());
+                }
+                py::array_t<T, py::array::f_style> U({(py::ssize_t)mm, (py::ssize_t)r}), V({(py::ssize_t)r, (py::ssize_t)nn});
+                if (r > 0) check(htool_hmatrix_leaf_panels(s.h, i, U.mutable_data(), V.mutable_data()));
+                return py::make_tuple(U, V);
+            })
+        .def("stats", [](const H &s) {
+                int64_t st[8];
+                htool_hmatrix_stats(s.h, st);
+                py::dict d;
+                d["dense_elements"] = st[0]; d["low_rank_elements"] = st[1]; d["n_dense"] = st[2]; d["n_low_rank"] = st[3];
+                d["sum_rank"] = st[4]; d["hbm_bytes"] = st[5]; d["build_seconds"] = st[6] * 1e-6; d["max_rank"] = st[7];
+                return d;
+            })
+        .def("last_product_us", [](const H &s) { return htool_hmatrix_last_product_us(s.h); })
+        .def("matvec_device", [](const H &s, std::uintptr_t x_dev, std::uintptr_t y_dev, int numbering, std::uintptr_t stream) {
+                check(htool_hmatrix_matvec_device(s.h, (const void *)x_dev, (void *)y_dev, numbering, (void *)stream));
+            }, "x_ptr"_a, "y_ptr"_a, "numbering"_a = 0, "stream"_a = 0)
+        .def_property_readonly("_handle", [](const H &s) { return (std::uintptr_t)s.h; });
+
+    m.def("recompression", [](H &) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
+    m.def("recompression", [](H &, py::object) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
+    m.def("openmp_recompression", [](H &) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
+    m.def("openmp_recompression", [](H &, py::object) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
+
+    // HMatrixTreeBuilder (hmatrix/hmatrix_tree_builder.hpp:10-44)
+    typedef PyHMatrixTreeBuilder<T> B;
+    py::class_<B>(m, (prefix + "HMatrixTreeBuilder").c_str())
+        .def(py::init<double, double, char, char, int, std::shared_ptr<PyVirtualLowRankGenerator<T>>>(), "epsilon"_a, "eta"_a, "symmetry"_a, "UPLO"_a, py::kw_only(),
+             "reqrank"_a = -1, "low_rank_strategy"_a = nullptr)
+        .def("build", &B::build, "generator"_a, "target_cluster"_a, "source_cluster"_a, "target_partition_number"_a = -1, "partition_number_for_symmetry"_a = -1)
+        .def("set_minimal_source_depth", [](B &b, int d) { b.p.minimal_source_depth = d; })
+        .def("set_minimal_target_depth", [](B &b, int d) { b.p.minimal_target_depth = d; })
+        .def("set_low_rank_generator", [](B &b, std::shared_ptr<PyVirtualLowRankGenerator<T>> g) { b.low_rank = g; })
+        .def("set_dense_blocks_generator", [](B &b, std::shared_ptr<PyVirtualDenseBlocksGenerator<T>> g) { b.dense_blocks = g; })
+        .def("set_block_tree_consistency", [](B &b, bool c) { b.p.block_tree_consistency = c ? 1 : 0; });
+
+    // DistributedOperator + DefaultApproximationBuilder (distributed_operator/*.hpp)
+    typedef PyDistributedOperator<T> Op;
+    py::class_<Op>(m, (prefix + "DistributedOperator").c_str())
+        .def_property_readonly("shape", [](const Op &o) {
+                int r, c;
+                htool_distributed_shape(o.d, &r, &c);
+                return std::pair<int, int>(r, c);
+            })
+        .def("__mul__", &Op::mul, "in"_a)
+        .def("__matmul__", &Op::matmul, py::arg("input").noconvert(true));
+    typedef PyDefaultApproximationBuilder<T> DA;
+    py::class_<DA>(m, (prefix + "DefaultApproximationBuilder").c_str())
+        .def(py::init<PyIGenerator<T> &, const PyCluster &, const PyCluster &, const B &, py::object>())
+        .def_property_readonly("distributed_operator", [](DA &s) { return &s.op; }, py::return_value_policy::reference_internal)
+        .def_property_readonly("hmatrix", [](DA &s) { return &s.hmat; }, py::return_value_policy::reference_internal)
+        .def_property_readonly("block_diagonal_hmatrix", [](DA &) { return py::none(); });
+}
+
+PYBIND11_MODULE(Htool, m) {
+    m.doc() = "MI355X-native H-matrix engine behind the Htool Python API";
+    htool_set_log_sink(&python_log_sink);
+    m.def("test_logger", &htool_test_logger);
+    m.def("device_count", &htool_device_count);
+    m.def("device_name", []() { return std::string(htool_device_name()); });
+    m.def("set_device", [](int d) { check(htool_set_device(d)); });
+
+    py::class_<PyCluster>(m, "Cluster")
+        .def("get_size", [](const PyCluster &c) { return htool_cluster_size(c.node); })
+        .def("get_offset", [](const PyCluster &c) { return htool_cluster_offset(c.node); })
+        .def("get_maximal_leaf_size", [](const PyCluster &c) { return htool_cluster_maximal_leaf_size(c.node); })
+        .def("get_permutation", [](py::object self) {
+                const PyCluster &c = self.cast<const PyCluster &>();
+                int n = 0;
+                const int *p = htool_cluster_permutation(c.node, &n);
+                return py::array_t<int>(std::array<py::ssize_t, 1>{n}, p, self); // view; keeps the cluster alive
+            })
+        .def("get_cluster_on_partition", [](const PyCluster &c, int p) {
+                const htool_cluster *s = htool_cluster_on_partition(c.node, p);
+                if (!s) throw std::runtime_error(htool_last_error());
+                return PyCluster{c.owner, s};
+            })
+        .def("_nodes", [](const PyCluster &c) {
+                int n = htool_cluster_node_count(c.node);
+                py::array_t<int> ints({(py::ssize_t)n, (py::ssize_t)7});
+                py::array_t<double> dbl({(py::ssize_t)n, (py::ssize_t)4});
+                htool_cluster_nodes(c.node, ints.mutable_data(), dbl.mutable_data());
+                return py::make_tuple(ints, dbl);
+            })
+        .def("_node_id", [](const PyCluster &c) { return htool_cluster_node_id(c.node); });
+
+    py::class_<PyPartitioning, std::shared_ptr<PyPartitioning>>(m, "VirtualPartitioning");
+    py::class_<PyPartitioningT<HTOOL_PCA_REGULAR>, std::shared_ptr<PyPartitioningT<HTOOL_PCA_REGULAR>>, PyPartitioning>(m, "PCARegular").def(py::init<>());
+    py::class_<PyPartitioningT<HTOOL_PCA_GEOMETRIC>, std::shared_ptr<PyPartitioningT<HTOOL_PCA_GEOMETRIC>>, PyPartitioning>(m, "PCAGeometric").def(py::init<>());
+    py::class_<PyPartitioningT<HTOOL_BBOX_REGULAR>, std::shared_ptr<PyPartitioningT<HTOOL_BBOX_REGULAR>>, PyPartitioning>(m, "BoundingBoxRegular").def(py::init<>());
+    py::class_<PyPartitioningT<HTOOL_BBOX_GEOMETRIC>, std::shared_ptr<PyPartitioningT<HTOOL_BBOX_GEOMETRIC>>, PyPartitioning>(m, "BoundingBoxGeometric").def(py::init<>());
+
+    typedef PyClusterTreeBuilder CB;
+    py::class_<CB>(m, "ClusterTreeBuilder")
+        .def(py::init<>())
+        .def("create_cluster_tree", [](CB &self, CB::coords_t coordinates, int number_of_children, std::optional<int> size_of_partition, std::optional<CB::coords_t> radii,
+                                       std::optional<CB::coords_t> weights) {
+                return self.create(coordinates, number_of_children, size_of_partition ? *size_of_partition : number_of_children, nullptr, false, radii, weights);
+            }, "coordinates"_a, "number_of_children"_a, py::kw_only(), "size_of_partition"_a = py::none(), "radii"_a = py::none(), "weights"_a = py::none())
+        .def("create_cluster_tree_from_global_partition", [](CB &self, CB::coords_t coordinates, int number_of_children, int size_of_partition, CB::part_t partition,
+                                                             std::optional<CB::coords_t> radii, std::optional<CB::coords_t> weights) {
+                if (partition.ndim() != 1 || partition.shape(0) != coordinates.shape(1)) throw std::runtime_error("Wrong format for partition");
+                return self.create(coordinates, number_of_children, size_of_partition, partition.data(), false, radii, weights);
+            }, "coordinates"_a, "number_of_children"_a, "size_of_partition"_a, "partition"_a, py::kw_only(), "radii"_a = py::none(), "weights"_a = py::none())
+        .def("create_cluster_tree_from_local_partition", [](CB &self, CB::coords_t coordinates, int number_of_children, int size_of_partition, CB::part_t partition,
+                                                            std::optional<CB::coords_t> radii, std::optional<CB::coords_t> weights) {
+                if (partition.ndim() != 2 || partition.shape(0) != 2 || partition.shape(1) != size_of_partition) throw std::runtime_error("Wrong format for partition");
+                return self.create(coordinates, number_of_children, size_of_partition, partition.data(), true, radii, weights);
+            }, "coordinates"_a, "number_of_children"_a, "size_of_partition"_a, "partition"_a, py::kw_only(), "radii"_a = py::none(), "weights"_a = py::none())
+        .def("set_maximal_leaf_size", [](CB &self, int s) { self.max_leaf = s; })
+        .def("set_partitioning_strategy", [](CB &self, std::shared_ptr<PyPartitioning> p) { self.strategy = p->strategy; });
+
+    declare_coefficient_classes<double>(m, "", "IGenerator", "VirtualGenerator", "VirtualLowRankGenerator", "NativeGenerator");
+    declare_coefficient_classes<std::complex<double>>(m, "Complex", "IComplexGenerator", "ComplexVirtualGenerator", "VirtualComplexLowRankGenerator", "ComplexNativeGenerator");
+}

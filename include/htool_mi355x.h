@@ -1,0 +1,182 @@
+/* htool_mi355x.h -- C ABI of libhtool_mi355x.so, the MI355X (gfx950) H-matrix engine.
+ *
+ * This is the drop-in boundary for the H-matrix build + matvec hot path of
+ * htool-ddm/htool_python.  Every entry point replaces a call the reference's pybind11
+ * translation unit (src/htool/main.cpp) makes into the un-vendored C++ core lib/htool; the
+ * replaced call site is cited (path:line relative to the reference repository) next to each
+ * declaration.  Plain pointers and sizes only; no torch / pybind11 / STL types cross this line.
+ *
+ * Conventions (all visible at the reference's binding layer):
+ *   - coordinates are point-major, dim doubles per point (cluster_tree_builder.hpp:19-23)
+ *   - permutation[i] = user index of the point at cluster position i
+ *   - generators are called with USER indices and write column-major blocks
+ *     (hmatrix/interfaces/virtual_generator.hpp:16-25)
+ *   - products take and return USER-numbered vectors (hmatrix/hmatrix.hpp:101-117)
+ *   - complex data is interleaved (re, im) double pairs; "void*" data pointers are double* or
+ *     double(*)[2] according to the object's is_complex flag
+ *   - every function returning int returns 0 on success, non-zero on error; the message is
+ *     available from htool_last_error() (thread-local).  The shim rethrows it as RuntimeError.
+ *   - the compute path is HIP only: if no gfx950 device is usable, build/product calls FAIL
+ *     (there is no CPU fallback inside the library).
+ */
+#ifndef HTOOL_MI355X_H
+#define HTOOL_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct htool_cluster htool_cluster;         /* a node of a cluster tree; the root owns the tree */
+typedef struct htool_generator htool_generator;     /* entry generator A(i,j) */
+typedef struct htool_hmatrix htool_hmatrix;         /* flattened H-matrix resident in HBM */
+typedef struct htool_distributed htool_distributed; /* row-partitioned operator (one rank per GPU) */
+
+/* ---- errors, device, logging -------------------------------------------------------------- */
+const char *htool_last_error(void);
+int htool_device_count(void);          /* number of usable HIP devices (0 on a GPU-less box) */
+int htool_set_device(int device);      /* select the HIP device for objects created afterwards */
+const char *htool_device_name(void);   /* e.g. "gfx950:..." or "" */
+
+/* replaces PythonLoggerWriter / htool::Logger (misc/logger.hpp:10-37, main.cpp:42).
+ * levels: 0 CRITICAL, 1 ERROR, 2 WARNING, 3 DEBUG, 4 INFO (order of logger.hpp:17-32) */
+typedef void (*htool_log_sink)(int level, const char *message);
+void htool_set_log_sink(htool_log_sink sink);
+void htool_test_logger(void); /* misc/testing.hpp:5-11 */
+
+/* ---- cluster tree (clustering/cluster_tree_builder.hpp:19-67, cluster_node.hpp:18-26) ------- */
+enum { HTOOL_PCA_REGULAR = 0, HTOOL_PCA_GEOMETRIC = 1, HTOOL_BBOX_REGULAR = 2, HTOOL_BBOX_GEOMETRIC = 3 }; /* main.cpp:54-57 */
+
+/* partition: NULL | n labels (partition_is_local=0, cluster_tree_builder.hpp:32-39)
+ *                 | size_of_partition (offset,size) pairs (partition_is_local=1, :49-56) */
+int htool_cluster_create(const double *coordinates, int n_points, int dim, const double *radii, const double *weights,
+                         int number_of_children, int size_of_partition, const int *partition, int partition_is_local,
+                         int maximal_leaf_size, int strategy, htool_cluster **out);
+void htool_cluster_destroy(htool_cluster *root);
+int htool_cluster_size(const htool_cluster *c);                                   /* cluster_node.hpp:18 */
+int htool_cluster_offset(const htool_cluster *c);                                 /* :19 */
+int htool_cluster_maximal_leaf_size(const htool_cluster *c);                      /* :20 */
+const int *htool_cluster_permutation(const htool_cluster *c, int *n);             /* :21-25, borrowed, whole tree */
+const htool_cluster *htool_cluster_on_partition(const htool_cluster *c, int p);   /* :26, borrowed */
+int htool_cluster_dimension(const htool_cluster *c);
+/* introspection used by plotting and tests: node table of the whole tree.
+ * ints per node: offset,size,depth,parent,first_child,n_children,partition; doubles: cx,cy,cz,radius */
+int htool_cluster_node_count(const htool_cluster *c);
+int htool_cluster_node_id(const htool_cluster *c);
+void htool_cluster_nodes(const htool_cluster *c, int *ints7, double *doubles4);
+
+/* ---- generators (hmatrix/interfaces/virtual_generator.hpp:16-25) ----------------------------- */
+/* callback flavour: out is column-major M x N, rows/cols in user numbering.  Only ever invoked on
+ * the thread that entered the library (ctx is typically a Python object needing the GIL). */
+typedef void (*htool_copy_submatrix_fn)(void *ctx, int M, int N, const int *rows, const int *cols, void *out);
+int htool_generator_create_callback(int is_complex, htool_copy_submatrix_fn fn, void *ctx, htool_generator **out);
+
+/* native flavour: evaluated on the device.  kinds: */
+enum {
+    HTOOL_KERNEL_INV_DELTA = 0, /* 1/(param + |x-y|)            (example/define_generators.py:14-17, param=0.1) */
+    HTOOL_KERNEL_LAPLACE   = 1, /* 1/(4 pi |x-y|), 0 at x==y     */
+    HTOOL_KERNEL_HELMHOLTZ = 2  /* exp(i param |x-y|)/(4 pi |x-y|), 0 at x==y; complex */
+};
+int htool_generator_create_native(int kind, int dim, const double *target_points, int n_target, const double *source_points,
+                                  int n_source, double param, htool_generator **out);
+int htool_generator_is_complex(const htool_generator *g);
+void htool_generator_destroy(htool_generator *g);
+
+/* ---- builder hooks ---------------------------------------------------------------------------- */
+/* custom compressor (hmatrix/interfaces/virtual_low_rank_generator.hpp:25-45): return 1 and set
+ * U (M x rank, column-major), V (rank x N, column-major) on success, 0 when not worthwhile.
+ * The library copies U and V before the next call. */
+typedef int (*htool_compress_fn)(void *ctx, int M, int N, const int *rows, const int *cols, double epsilon,
+                                 const void **U, const void **V, int *rank);
+/* batched dense fill (hmatrix/interfaces/virtual_dense_blocks_generator.hpp:21-35): block i is
+ * M[i] x N[i] column-major at ptrs[i]; its rows are permutation_t[row_offsets[i] ...], same for cols. */
+typedef void (*htool_dense_blocks_fn)(void *ctx, int n_blocks, const int *M, const int *N, const int *row_offsets,
+                                      const int *col_offsets, void **ptrs);
+
+/* parameters of HMatrixTreeBuilder (hmatrix/hmatrix_tree_builder.hpp:23-43) */
+typedef struct htool_build_params {
+    double epsilon;
+    double eta;
+    char symmetry; /* 'N','S','H' */
+    char uplo;     /* 'N','L','U' */
+    int reqrank;   /* -1: epsilon-driven */
+    int minimal_target_depth;
+    int minimal_source_depth;
+    int block_tree_consistency;
+    htool_compress_fn compress;         /* NULL: built-in partial-pivot ACA */
+    void *compress_ctx;
+    htool_dense_blocks_fn dense_blocks; /* NULL: generator */
+    void *dense_blocks_ctx;
+} htool_build_params;
+void htool_build_params_default(htool_build_params *p);
+
+/* ---- H-matrix (hmatrix/hmatrix_tree_builder.hpp:36, hmatrix/hmatrix.hpp:31-138) ---------------- */
+/* HMatrixTreeBuilder.build(generator, target, source, target_partition_number, partition_number_for_symmetry).
+ * The cluster roots must outlive the H-matrix (as in the reference, which stores references). */
+int htool_hmatrix_build(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
+                        const htool_build_params *params, int target_partition_number, int partition_number_for_symmetry,
+                        htool_hmatrix **out);
+void htool_hmatrix_destroy(htool_hmatrix *h);
+int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out); /* __deepcopy__, hmatrix.hpp:48 */
+int htool_hmatrix_is_complex(const htool_hmatrix *h);
+int htool_hmatrix_nb_rows(const htool_hmatrix *h); /* hmatrix.hpp:31: size of the target cluster it was built on */
+int htool_hmatrix_nb_cols(const htool_hmatrix *h);
+const htool_cluster *htool_hmatrix_target_cluster(const htool_hmatrix *h); /* hmatrix.hpp:55, borrowed */
+const htool_cluster *htool_hmatrix_source_cluster(const htool_hmatrix *h); /* hmatrix.hpp:56, borrowed */
+
+/* y = alpha * op(H) x + beta * y, host pointers, USER numbering; replaces
+ * htool::add_hmatrix_vector_product (hmatrix.hpp:113).  trans: 'N' only. */
+int htool_hmatrix_matvec(const htool_hmatrix *h, char trans, const void *alpha, const void *x, const void *beta, void *y);
+/* Y = alpha H X + beta Y, X column-major n_cols x mu; replaces add_hmatrix_matrix_product (hmatrix.hpp:134) */
+int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, const void *X, int mu, const void *beta, void *Y);
+/* device-pointer variants for GPU-resident loops (Krylov, distributed bench): y = H x with
+ * x (n_cols) and y (rows of this H-matrix) device buffers.  numbering: 0 = user, 1 = cluster
+ * (cluster: x is the whole permuted source vector, y the local row slice).  stream = hipStream_t. */
+int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream);
+
+/* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
+int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);
+
+/* flattened leaf list: 5 ints per leaf {t_off, m, s_off, n, rank}, rank -1 = dense
+ * (matplotlib/hmatrix.hpp:13-24,65-67) */
+int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h);
+void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5);
+/* panels of one leaf copied from HBM to host: dense -> A (m x n col-major); low rank -> A = U (m x r
+ * col-major), B = V (r x n col-major).  Used by parity tests and plotting; not a hot path. */
+int htool_hmatrix_leaf_panels(const htool_hmatrix *h, int64_t leaf, void *A, void *B);
+
+/* get_tree_parameters / get_local_information (hmatrix.hpp:50-52): "key=value\n" lines copied
+ * into buf (truncated to cap); returns needed size. which: 0 tree parameters, 1 local information */
+int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap);
+/* numeric statistics for roofline accounting: out[0]=dense elements, out[1]=low-rank
+ * elements sum r(m+n), out[2]=n dense leaves, out[3]=n low-rank leaves, out[4]=sum of ranks,
+ * out[5]=bytes resident in HBM, out[6]=build seconds*1e6, out[7]=max rank */
+void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8);
+/* time of the kernels of the last product in microseconds (HIP events), -1 if none */
+double htool_hmatrix_last_product_us(const htool_hmatrix *h);
+
+/* ---- distributed operator (distributed_operator/utility.hpp:25-32, distributed_operator.hpp:18-65) */
+/* communicator supplied by the host language (mpi4py stand-in; backed by torch.distributed/RCCL or gloo).
+ * allgatherv works on HOST buffers of bytes. */
+typedef struct htool_comm {
+    int rank, size;
+    void *ctx;
+    int (*allgatherv)(void *ctx, const void *send, int64_t send_bytes, void *recv, const int64_t *recv_bytes, const int64_t *displs);
+} htool_comm;
+
+/* DefaultApproximationBuilder: builds rows(partition rank) x all columns */
+int htool_distributed_create_default(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
+                                     const htool_build_params *params, const htool_comm *comm, htool_distributed **out);
+void htool_distributed_destroy(htool_distributed *d);
+htool_hmatrix *htool_distributed_hmatrix(htool_distributed *d);                /* utility.hpp:29, borrowed */
+htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *d); /* utility.hpp:31, borrowed */
+void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols); /* distributed_operator.hpp:18 */
+/* replicated user-numbered x in, replicated y out (distributed_operator.hpp:23-65) */
+int htool_distributed_matvec(const htool_distributed *d, const void *x, void *y);
+int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, void *Y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,90 @@
+import os
+
+import numpy as np
+
+SUM, MAX, MIN = "sum", "max", "min"
+
+
+class _Comm:
+    def __init__(self):
+        self._pg_ready = False
+
+    # -- identity (from the torchrun environment; a plain `python script.py` is a world of one)
+    @property
+    def size(self):
+        return int(os.environ.get("WORLD_SIZE", "1"))
+
+    @property
+    def rank(self):
+        return int(os.environ.get("RANK", "0"))
+
+    def Get_size(self):
+        return self.size
+
+    def Get_rank(self):
+        return self.rank
+
+    def _dist(self):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.size)
+        return dist
+
+    def _host_group(self):
+        """gloo group for host buffers (the default group may be nccl in GPU benches)."""
+        dist = self._dist()
+        if dist.get_backend() == "gloo":
+            return None
+        if not hasattr(self, "_gloo"):
+            self._gloo = dist.new_group(backend="gloo")
+        return self._gloo
+
+    def Barrier(self):
+        if self.size > 1:
+            self._dist().barrier(group=self._host_group())
+
+    barrier = Barrier
+
+    def allreduce(self, value, op=SUM):
+        if self.size == 1:
+            return value
+        import torch
+
+        dist = self._dist()
+        t = torch.tensor(np.asarray(value, dtype=np.float64))
+        dist.all_reduce(t, op={SUM: dist.ReduceOp.SUM, MAX: dist.ReduceOp.MAX, MIN: dist.ReduceOp.MIN}[op], group=self._host_group())
+        out = t.numpy()
+        if np.isscalar(value) or np.ndim(value) == 0:
+            return type(value)(out.item()) if isinstance(value, (int, float)) else out.item()
+        return out
+
+    def bcast(self, obj, root=0):
+        if self.size == 1:
+            return obj
+        dist = self._dist()
+        box = [obj]
+        dist.broadcast_object_list(box, src=root, group=self._host_group())
+        return box[0]
+
+    # -- used by libhtool_mi355x through the pybind shim: all-gather of host byte slices
+    def _htool_allgatherv(self, send, recv, counts, displs):
+        if self.size == 1:
+            recv[displs[0]:displs[0] + counts[0]] = send
+            return
+        import torch
+
+        dist = self._dist()
+        pad = max(counts)
+        s = torch.zeros(pad, dtype=torch.uint8)
+        s[: len(send)] = torch.from_numpy(np.ascontiguousarray(send))
+        parts = [torch.empty(pad, dtype=torch.uint8) for _ in range(self.size)]
+        dist.all_gather(parts, s, group=self._host_group())
+        for p in range(self.size):
+            recv[displs[p]:displs[p] + counts[p]] = parts[p][: counts[p]].numpy()
+
+
+COMM_WORLD = _Comm()
+Comm = _Comm

@@ -1,0 +1,110 @@
+"""Shared helpers of the parity tests (host-language mirrors of the reference's example generators)."""
+import numpy as np
+
+import Htool
+from oracle import oracle as O
+
+
+class NumpyGenerator(Htool.VirtualGenerator):
+    """Callback generator: same kernel as the reference's CustomGenerator
+    (example/define_generators.py:6-27), evaluated block-wise with numpy instead of per entry."""
+
+    def __init__(self, target_points, source_points, kind=O.K_INV_DELTA, p0=0.1):
+        super().__init__()
+        self.target_points = target_points
+        self.source_points = source_points
+        self.kind, self.p0 = kind, p0
+        self.nb_rows = target_points.shape[1]
+        self.nb_cols = source_points.shape[1]
+
+    def build_submatrix(self, J, K, mat):
+        mat[:, :] = O.kernel_block(self.kind, self.target_points[:, J], self.source_points[:, K], self.p0)
+
+    def mat_vec(self, x):
+        return O.dense_matvec(self.kind, self.target_points, self.source_points, x, self.p0)
+
+    def mat_mat(self, X):
+        return O.dense_matvec(self.kind, self.target_points, self.source_points, X, self.p0)
+
+
+class ComplexNumpyGenerator(Htool.ComplexVirtualGenerator):
+    def __init__(self, target_points, source_points, kappa):
+        super().__init__()
+        self.target_points, self.source_points, self.kappa = target_points, source_points, kappa
+
+    def build_submatrix(self, J, K, mat):
+        mat[:, :] = O.kernel_block(O.K_HELMHOLTZ, self.target_points[:, J], self.source_points[:, K], self.kappa)
+
+    def mat_vec(self, x):
+        return O.dense_matvec(O.K_HELMHOLTZ, self.target_points, self.source_points, x, self.kappa)
+
+
+class CustomSVD(Htool.VirtualLowRankGenerator):
+    """Truncated-SVD compressor with the acceptance rule of the reference's example
+    (example/advanced/define_custom_low_rank_generator.py:13-31)."""
+
+    def __init__(self, generator, allow_copy=True):
+        super().__init__(allow_copy)
+        self.generator = generator
+
+    def build_low_rank_approximation(self, rows, cols, epsilon):
+        submat = np.zeros((len(rows), len(cols)), order="F")
+        self.generator.build_submatrix(rows, cols, submat)
+        u, s, vh = np.linalg.svd(submat, full_matrices=False)
+        norm = np.linalg.norm(submat)
+        svd_norm = 0
+        truncated_rank = len(s) - 1
+        while truncated_rank > 0 and np.sqrt(svd_norm) / norm < epsilon:
+            svd_norm += s[truncated_rank] ** 2
+            truncated_rank -= 1
+        truncated_rank += 1
+        if truncated_rank * (len(rows) + len(cols)) > len(rows) * len(cols):
+            return False
+        self.set_U(u[:, 0:truncated_rank] * s[0:truncated_rank])
+        self.set_V(vh[0:truncated_rank, :])
+        return True
+
+
+class CustomDenseBlocksGenerator(Htool.VirtualDenseBlocksGenerator):
+    """example/advanced/define_custom_dense_blocks_generator.py"""
+
+    def __init__(self, generator, target_cluster, source_cluster):
+        super().__init__(target_cluster, source_cluster)
+        self.generator = generator
+
+    def build_dense_blocks(self, rows_offsets, cols_offsets, blocks):
+        for i in range(len(blocks)):
+            self.generator.build_submatrix(rows_offsets[i], cols_offsets[i], blocks[i])
+
+
+def cluster_of(points, max_leaf=10, children=2, **kw):
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(max_leaf)
+    return b.create_cluster_tree(points, children, **kw)
+
+
+def cpu_leaf_loop(hmatrix, x_user, is_complex=False):
+    """Download every leaf's panels from HBM and run the oracle's CPU leaf loop on them:
+    y (user numbering) = sum over leaves, on panels IDENTICAL to what the HIP product streams."""
+    leaves = np.asarray(hmatrix.leaves())
+    tc, sc = hmatrix.get_target_cluster(), hmatrix.get_source_cluster()
+    pt, ps = np.asarray(tc.get_permutation()), np.asarray(sc.get_permutation())
+    dt = np.complex128 if is_complex else np.float64
+    chunks, offs, pos = [], np.zeros((len(leaves), 2), dtype=np.int64), 0
+    for i, (t_off, m, s_off, n, r) in enumerate(leaves):
+        A, B = hmatrix.leaf_panels(i)
+        a = np.asarray(A, dtype=dt).ravel(order="F")  # dense: m x n col-major; low rank: U m x r col-major
+        offs[i, 0] = pos
+        chunks.append(a)
+        pos += a.size
+        offs[i, 1] = pos
+        if r >= 0:
+            v = np.ascontiguousarray(np.asarray(B, dtype=dt)).ravel()  # r x n, step-major (each V row contiguous)
+            chunks.append(v)
+            pos += v.size
+    panels = np.concatenate(chunks) if chunks else np.zeros(0, dtype=dt)
+    xp = np.asarray(x_user, dtype=dt)[ps]
+    yp = O.leaf_loop(leaves, offs, panels, len(pt), xp, is_complex)
+    y = np.zeros(len(pt), dtype=dt)
+    y[pt] = yp
+    return y

@@ -1,0 +1,168 @@
+"""GPU parity tests of the H-matrix product (hot-path rows a9-a12 of SURVEY.md section 8).
+
+Mirrors the assertions of the reference's tests/test_hmatrix.py:67,83-85,94-96 (same geometry seed,
+sizes, eta, epsilon, leaf size; our own harness) and adds the oracle checks: HIP product vs CPU leaf
+loop on identical panels (<= 1e-12), vs the exact dense kernel (< epsilon).
+"""
+import copy
+import logging
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("symmetry", ["N", "S"])
+@pytest.mark.parametrize("custom_svd", [True, False])
+def test_hmatrix_reference_case(built, oracle, symmetry, custom_svd):
+    import Htool
+    from tests.helpers import CustomSVD, NumpyGenerator, cluster_of
+
+    logging.basicConfig(level=logging.INFO)
+    O = oracle
+    nb_rows = nb_cols = 500
+    target_points, source_points = O.random_geometries(3, nb_rows, nb_cols)  # seed 0, source shifted by +2
+    eta, epsilon = 100, 1e-3
+    target_cluster = cluster_of(target_points, 10)
+    if symmetry == "N":
+        source_cluster = cluster_of(source_points, 10)
+        generator = NumpyGenerator(target_points, source_points)
+    else:
+        source_cluster = target_cluster
+        generator = NumpyGenerator(target_points, target_points)
+    builder = Htool.HMatrixTreeBuilder(epsilon, eta, "N", "N")
+    lr = None
+    if custom_svd:
+        lr = CustomSVD(generator, False)
+        builder.set_low_rank_generator(lr)
+    hmatrix = builder.build(generator, target_cluster, source_cluster)
+    assert hmatrix.shape == (nb_rows, nb_cols)
+    copy_hmatrix = copy.deepcopy(hmatrix)
+    _ = hmatrix.to_dense()
+    dense_user = hmatrix.to_dense_in_user_numbering()
+
+    np.random.seed(0)
+    x = np.random.rand(nb_cols)
+    y = hmatrix * x
+    y_exact = generator.mat_vec(x)
+    y_dense = dense_user.dot(x)
+    y_copy = copy_hmatrix * x
+    assert np.linalg.norm(y - y_exact) / np.linalg.norm(y_exact) < epsilon
+    assert np.linalg.norm(y - y_dense) / np.linalg.norm(y_dense) < 1e-10
+    assert np.linalg.norm(y - y_copy) < 1e-10
+
+    np.random.seed(0)
+    X = np.random.rand(nb_cols, 2)
+    Y = hmatrix @ X
+    Y_exact = generator.mat_mat(X)
+    assert np.linalg.norm(Y - Y_exact) / np.linalg.norm(Y_exact) < epsilon
+    assert np.linalg.norm(Y - dense_user @ X) / np.linalg.norm(dense_user @ X) < 1e-10
+    assert np.linalg.norm(Y - copy_hmatrix @ X) < 1e-10
+
+    # densified in cluster numbering == permuted user-numbered one
+    pt, ps = np.asarray(target_cluster.get_permutation()), np.asarray(source_cluster.get_permutation())
+    assert np.allclose(hmatrix.to_dense(), dense_user[np.ix_(pt, ps)], rtol=0, atol=1e-13)
+
+    print(hmatrix.get_tree_parameters())
+    print(hmatrix.get_local_information())
+    if lr is not None:
+        lr.clear_data()
+
+    with pytest.raises(RuntimeError, match="Wrong size for HMatrix-vector product"):
+        hmatrix * np.zeros(nb_cols + 1)
+    with pytest.raises(RuntimeError, match="Wrong dimension for HMatrix-vector product"):
+        hmatrix * np.zeros((nb_cols, 1))
+
+
+@pytest.mark.parametrize("n,leaf,eta,epsilon", [(3000, 10, 10.0, 1e-3), (6000, 64, 10.0, 1e-4), (5000, 100, 3.0, 1e-6)])
+def test_product_vs_cpu_leaf_loop_and_dense(built, oracle, n, leaf, eta, epsilon):
+    """HIP product vs (i) the CPU leaf loop on the SAME panels, (ii) the exact dense operator."""
+    import Htool
+    from tests.helpers import NumpyGenerator, cluster_of, cpu_leaf_loop
+
+    O = oracle
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, leaf)
+    gen = NumpyGenerator(pts, pts, O.K_LAPLACE, 0.0)
+    H = Htool.HMatrixTreeBuilder(epsilon, eta, "N", "N").build(gen, cl, cl)
+    np.random.seed(0)
+    x = np.random.rand(n)
+    y = H * x
+    y_cpu = cpu_leaf_loop(H, x)
+    assert np.linalg.norm(y - y_cpu) / np.linalg.norm(y_cpu) < 1e-12
+    y_exact = gen.mat_vec(x)
+    assert np.linalg.norm(y - y_exact) / np.linalg.norm(y_exact) < epsilon
+    # bitwise reproducible (fixed summation order, no atomics)
+    assert np.array_equal(y, H * x)
+    # linearity (size-independent property)
+    z = np.random.rand(n)
+    assert np.linalg.norm(H * (2.0 * x + z) - (2.0 * y + H * z)) / np.linalg.norm(y) < 1e-12
+    # leaves tile the matrix exactly once
+    L = np.asarray(H.leaves()).astype(np.int64)
+    assert (L[:, 1] * L[:, 3]).sum() == n * n
+
+
+def test_rectangular_and_host_aca_ranks_match_oracle(built, oracle):
+    """400 x 200 operator (tests/test_distributed_operator.py:25 shape); host-driven ACA (callback
+    generator) must reproduce the oracle's ranks leaf by leaf: same algorithm, same pivots."""
+    import Htool
+    from tests.helpers import NumpyGenerator, cluster_of
+
+    O = oracle
+    np.random.seed(0)
+    T, S = np.random.random((3, 400)), np.random.random((3, 200))
+    tcl, scl = cluster_of(T, 10), cluster_of(S, 10)
+    gen = NumpyGenerator(T, S)
+    for epsilon in (1e-3, 1e-6):
+        H = Htool.HMatrixTreeBuilder(epsilon, 10.0, "N", "N").build(gen, tcl, scl)
+        assert H.shape == (400, 200)
+        x = np.random.rand(200)
+        y = H * x
+        ye = gen.mat_vec(x)
+        assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < epsilon
+        otc, osc = O.Cluster(T, max_leaf=10), O.Cluster(S, max_leaf=10)
+        assert np.array_equal(otc.perm, np.asarray(tcl.get_permutation()))
+        assert np.array_equal(osc.perm, np.asarray(scl.get_permutation()))
+        OH = O.HMatrix(otc, osc, O.K_INV_DELTA, 0.1, eps=epsilon, eta=10.0)
+        mine = {tuple(l[:4]): l[4] for l in np.asarray(H.leaves())}
+        theirs = {tuple(l[:4]): l[4] for l in OH.leaves}
+        assert mine == theirs
+        assert np.linalg.norm(y - OH.matvec(x)) / np.linalg.norm(ye) < 1e-12
+
+
+def test_complex_product(built, oracle):
+    import Htool
+    from tests.helpers import ComplexNumpyGenerator, cluster_of, cpu_leaf_loop
+
+    O = oracle
+    n = 3000
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 32)
+    gen = ComplexNumpyGenerator(pts, pts, 5.0)
+    H = Htool.ComplexHMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(gen, cl, cl)
+    x = np.random.rand(n) + 1j * np.random.rand(n)
+    y = H * x
+    y_cpu = cpu_leaf_loop(H, x, True)
+    assert np.linalg.norm(y - y_cpu) / np.linalg.norm(y_cpu) < 1e-12
+    ye = gen.mat_vec(x)
+    assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < 1e-4
+
+
+def test_custom_dense_blocks_generator(built, oracle):
+    import Htool
+    from tests.helpers import CustomDenseBlocksGenerator, CustomSVD, NumpyGenerator, cluster_of
+
+    np.random.seed(0)
+    T, S = np.random.random((2, 400)), np.random.random((2, 400))
+    tcl, scl = cluster_of(T, 10), cluster_of(S, 10)
+    gen = NumpyGenerator(T, S)
+    b = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N")
+    b.set_dense_blocks_generator(CustomDenseBlocksGenerator(gen, tcl, scl))
+    b.set_low_rank_generator(CustomSVD(gen))
+    H = b.build(gen, tcl, scl)
+    x = np.random.rand(400)
+    ye = gen.mat_vec(x)
+    assert np.linalg.norm(H * x - ye) / np.linalg.norm(ye) < 1e-6
