@@ -54,7 +54,7 @@ def build(force=False):
     for s in HIP_SOURCES:
         src, obj = os.path.join(SRC, s), os.path.join(OBJ, s + ".o")
         if force or _newer(obj, [src] + hdrs):
-            _run([HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-Wall", "-Wno-unused-result", "-c", src, "-o", obj])
+            _run([HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result", "-c", src, "-o", obj])
         objs.append(obj)
     if force or _newer(LIB, objs):
         _run(["g++", "-shared", "-o", LIB] + objs + ["-fopenmp", "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")])

@@ -270,6 +270,7 @@ struct PyHMatrixTreeBuilder {
     htool_build_params p;
     std::shared_ptr<PyVirtualLowRankGenerator<T>> low_rank;
     std::shared_ptr<PyVirtualDenseBlocksGenerator<T>> dense_blocks;
+    py::object low_rank_ref, dense_blocks_ref; // keep the Python subclasses (and their overrides) alive
     PyHMatrixTreeBuilder(double epsilon, double eta, char symmetry, char UPLO, int reqrank, std::shared_ptr<PyVirtualLowRankGenerator<T>> lr) : low_rank(lr) {
         htool_build_params_default(&p);
         p.epsilon = epsilon;
@@ -471,13 +472,18 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
     // HMatrixTreeBuilder (hmatrix/hmatrix_tree_builder.hpp:10-44)
     typedef PyHMatrixTreeBuilder<T> B;
     py::class_<B>(m, (prefix + "HMatrixTreeBuilder").c_str())
-        .def(py::init<double, double, char, char, int, std::shared_ptr<PyVirtualLowRankGenerator<T>>>(), "epsilon"_a, "eta"_a, "symmetry"_a, "UPLO"_a, py::kw_only(),
-             "reqrank"_a = -1, "low_rank_strategy"_a = nullptr)
+        .def(py::init([](double epsilon, double eta, char symmetry, char UPLO, int reqrank, py::object low_rank_strategy) {
+                 std::shared_ptr<PyVirtualLowRankGenerator<T>> lr;
+                 if (!low_rank_strategy.is_none()) lr = low_rank_strategy.cast<std::shared_ptr<PyVirtualLowRankGenerator<T>>>();
+                 auto b = std::make_unique<B>(epsilon, eta, symmetry, UPLO, reqrank, lr);
+                 if (lr) b->low_rank_ref = low_rank_strategy;
+                 return b;
+             }), "epsilon"_a, "eta"_a, "symmetry"_a, "UPLO"_a, py::kw_only(), "reqrank"_a = -1, "low_rank_strategy"_a = py::none())
         .def("build", &B::build, "generator"_a, "target_cluster"_a, "source_cluster"_a, "target_partition_number"_a = -1, "partition_number_for_symmetry"_a = -1)
         .def("set_minimal_source_depth", [](B &b, int d) { b.p.minimal_source_depth = d; })
         .def("set_minimal_target_depth", [](B &b, int d) { b.p.minimal_target_depth = d; })
-        .def("set_low_rank_generator", [](B &b, std::shared_ptr<PyVirtualLowRankGenerator<T>> g) { b.low_rank = g; })
-        .def("set_dense_blocks_generator", [](B &b, std::shared_ptr<PyVirtualDenseBlocksGenerator<T>> g) { b.dense_blocks = g; })
+        .def("set_low_rank_generator", [](B &b, py::object g) { b.low_rank = g.cast<std::shared_ptr<PyVirtualLowRankGenerator<T>>>(); b.low_rank_ref = g; })
+        .def("set_dense_blocks_generator", [](B &b, py::object g) { b.dense_blocks = g.cast<std::shared_ptr<PyVirtualDenseBlocksGenerator<T>>>(); b.dense_blocks_ref = g; })
         .def("set_block_tree_consistency", [](B &b, bool c) { b.p.block_tree_consistency = c ? 1 : 0; });
 
     // DistributedOperator + DefaultApproximationBuilder (distributed_operator/*.hpp)
