@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""bench.py -- H-matvec GB/s (+ build seconds) for an N-point 3-D Laplace kernel on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json north_star / configs[3]): the 1 000 000-point 3-D Laplace single-layer
+operator 1/(4 pi r), points uniform in the unit ball (seed 0, construction of the reference's
+example/create_geometry.py:13-22), eta=10, eps=1e-3, binary PCA-regular cluster tree, fp64.
+A step is ONE H-matrix-vector product y = H x with x and y resident in HBM (user numbering in and
+out at N=1, exactly what `hmatrix * x` computes).  With N>1 the rows are split over the GPUs by the
+depth-1 partition of the cluster tree (DefaultApproximationBuilder's decomposition); a step is then an
+RCCL all-gather of the x slices followed by the local product (strong scaling: total work fixed).
+value = algorithmic bytes of all ranks / time; the roofline object prices the dominant
+kernel (phase B, tile_gemv_wide) with HIP events recorded on its stream inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; measured copy ceiling 6290)
+
+
+def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
+    """CPU leaf loop (oracle, OpenMP) on a bounded random sample of this operator's own leaves."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    rng = np.random.RandomState(0)
+    L = np.asarray(leaves, dtype=np.int64)
+    size = np.where(L[:, 4] < 0, L[:, 1] * L[:, 3], L[:, 4] * (L[:, 1] + L[:, 3])) * elem_bytes
+    order = rng.permutation(len(L))
+    cap_bytes, cap_leaves = 1.5e9, 12000
+    pick, tot = [], 0
+    for i in order:
+        if L[i, 4] == 0:
+            continue
+        if tot + size[i] > cap_bytes or len(pick) >= cap_leaves:
+            break
+        pick.append(i)
+        tot += int(size[i])
+    sel, offs, panels = O.leaf_sample_panels(H, pick)
+    # the full-size CPU loop pays (threads x N) for its thread-private y once per 85 GB of panels; keep
+    # that overhead proportionate for the sample by folding the sampled leaves' rows into a window
+    frac = tot / float(size.sum())
+    win = int(max(4 * frac * n_rows, sel[:, 1].max(), 4096))
+    sel = sel.copy()
+    sel[:, 0] = sel[:, 0] % (win - sel[:, 1] + 1)
+    n_rows = win
+    xp = rng.rand(n_source)
+    t_all, reps = [], 0
+    t_start = time.time()
+    while reps < 3 or (time.time() - t_start < budget_s and reps < 50):
+        t0 = time.perf_counter()
+        O.leaf_loop(sel, offs, panels, n_rows if n_rows > 0 else 1, xp)
+        t_all.append(time.perf_counter() - t0)
+        reps += 1
+    t_med = sorted(t_all)[len(t_all) // 2]
+    return {
+        "value": tot / t_med / 1e9,
+        "unit": "GB/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"CPU leaf loop (oracle/hmat_oracle.cpp, OpenMP) over {len(pick)} randomly drawn leaves of this operator "
+                  f"({tot / 1e9:.2f} GB of its {size.sum() / 1e9:.1f} GB of panels, downloaded from HBM), median of {reps} passes; "
+                  "the reference's own C++/MPI path (lib/htool) is not in the container",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=1_000_000, help="number of points")
+    ap.add_argument("--eps", type=float, default=1e-3)
+    ap.add_argument("--eta", type=float, default=10.0)
+    ap.add_argument("--leaf", type=int, default=100, help="maximal_leaf_size of the cluster tree")
+    ap.add_argument("--kernel", default="laplace", choices=["laplace", "inv_delta", "helmholtz"])
+    ap.add_argument("--kappa", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import Htool
+    from htool_python_amd.workloads import algorithmic_bytes, points_in_sphere
+
+    Htool.set_device(local_rank)
+    is_complex = args.kernel == "helmholtz"
+    elem = 16 if is_complex else 8
+    dtype = torch.complex128 if is_complex else torch.float64
+    n = args.n
+
+    pts = points_in_sphere(n, seed=0)
+    t0 = time.time()
+    cb = Htool.ClusterTreeBuilder()
+    cb.set_maximal_leaf_size(args.leaf)
+    cluster = cb.create_cluster_tree(pts, 2, size_of_partition=world)
+    t_cluster = time.time() - t0
+    param = {"laplace": 0.0, "inv_delta": 0.1, "helmholtz": args.kappa}[args.kernel]
+    if is_complex:
+        gen = Htool.ComplexNativeGenerator(args.kernel, pts, pts, param)
+        builder = Htool.ComplexHMatrixTreeBuilder(args.eps, args.eta, "N", "N")
+    else:
+        gen = Htool.NativeGenerator(args.kernel, pts, pts, param)
+        builder = Htool.HMatrixTreeBuilder(args.eps, args.eta, "N", "N")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    H = builder.build(gen, cluster, cluster, rank if world > 1 else -1)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    leaves = H.leaves()
+    n_rows = H.shape[0]
+    ab = algorithmic_bytes(leaves, n, n_rows, elem)
+    stats = H.stats()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    gen_t = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    if world == 1:
+        x = torch.rand(n, dtype=torch.float64, generator=gen_t)
+        if is_complex:
+            x = torch.complex(x, torch.rand(n, dtype=torch.float64, generator=gen_t))
+        x = x.cuda()
+        y = torch.zeros(n, dtype=dtype, device="cuda")
+
+        def step():
+            H.matvec_device(x.data_ptr(), y.data_ptr(), 0, stream)
+    else:
+        local = cluster.get_cluster_on_partition(rank)
+        sizes = [cluster.get_cluster_on_partition(p).get_size() for p in range(world)]
+        x_local = torch.rand(local.get_size(), dtype=torch.float64, generator=gen_t)
+        if is_complex:
+            x_local = torch.complex(x_local, torch.rand(local.get_size(), dtype=torch.float64, generator=gen_t))
+        x_local = x_local.cuda()
+        x_full = torch.zeros(n, dtype=dtype, device="cuda")
+        y = torch.zeros(n_rows, dtype=dtype, device="cuda")
+        equal = len(set(sizes)) == 1
+        parts = None if equal else list(torch.split(x_full, sizes))
+
+        def step():
+            # exchange: every GPU contributes its slice of x (cluster numbering), RCCL over xGMI
+            if equal:
+                dist.all_gather_into_tensor(x_full, x_local)
+            else:
+                dist.all_gather(parts, x_local)
+            H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_ph, ph = H.phase_times_us()
+
+    tot_bytes = float(ab["total"])
+    if world > 1:
+        t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, tot_bytes, t_build = float(tmax[0]), float(t[1]), float(tmax[2])
+    ms_per_step = dt / args.steps * 1e3
+    value = tot_bytes / (dt / args.steps) / 1e9
+
+    out = {
+        "metric": "h_matvec_GBps",
+        "value": value,
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "c128" if is_complex else "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n}-point 3D {args.kernel} H-matrix matvec (BASELINE configs[3] operator{' on one GPU' if world == 1 else ', row-cluster split'}), "
+                        f"eta={args.eta:g}, eps={args.eps:g}, leaf={args.leaf}, ACA on device, points seed 0 unit ball",
+            "n_points": n, "eps": args.eps, "eta": args.eta, "leaf": args.leaf, "kernel": args.kernel,
+            "parallelism": f"rows{world}" if world > 1 else "single",
+        },
+        "build_s": t_build,
+        "cluster_tree_s": t_cluster,
+        "algorithmic_GB": tot_bytes / 1e9,
+    }
+    if rank == 0:
+        t_b = ph[3] * 1e-6 if n_ph else None
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "tile_gemv_wide (phase B: U and dense panels)",
+            "achieved": (ab["phase_b"] / t_b / 1e9) if t_b else None,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": (ab["phase_b"] / t_b / 1e9 / HBM_PEAK_GBPS) if t_b else None,
+            "traffic": None,
+            "launch_us": ph[3] if n_ph else None,
+            "algorithmic_bytes_per_launch": ab["phase_b"],
+            "launches_averaged": n_ph,
+            "other_kernels_us": {"x_gather": ph[0], "phase_a_tile_gemv_tall": ph[1], "phase_a2_tile_gemv_tall": ph[2]} if n_ph else None,
+            "phase_a_achieved": (ab["phase_a"] / (ph[1] * 1e-6) / 1e9) if n_ph and ph[1] > 0 else None,
+        }
+        out["hmatrix"] = {"n_dense": stats["n_dense"], "n_low_rank": stats["n_low_rank"], "max_rank": stats["max_rank"],
+                          "mean_rank": stats["sum_rank"] / max(stats["n_low_rank"], 1), "hbm_resident_GB": stats["hbm_bytes"] / 1e9}
+        if args.check and world == 1:
+            from oracle import oracle as O
+
+            rows = np.arange(0, n, max(1, n // 256))
+            ye = O.dense_matvec({"laplace": 1, "inv_delta": 0, "helmholtz": 2}[args.kernel], pts, pts, x.cpu().numpy(), param, rows=rows)
+            yy = y.cpu().numpy()[rows]
+            out["rel_err_sampled_rows"] = float(np.linalg.norm(yy - ye) / np.linalg.norm(ye))
+        if world == 1 and not args.no_cpu_baseline and not is_complex:
+            out["cpu_baseline"] = cpu_baseline(H, leaves, n, n, elem)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

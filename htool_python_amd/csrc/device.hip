@@ -376,8 +376,7 @@ struct DeviceBuilder {
         D->row_off = H.row_off;
         D->row_size = H.row_size;
         HIP_OK(hipStreamCreate(&D->stream));
-        HIP_OK(hipEventCreate(&D->ev0));
-        HIP_OK(hipEventCreate(&D->ev1));
+        for (auto &slot : D->pev) for (auto &e : slot) HIP_OK(hipEventCreate(&e));
         d_rt_off = upload(H.rtiles.off);
         d_rt_size = upload(H.rtiles.size);
         d_ct_off = upload(H.ctiles.off);
@@ -555,19 +554,26 @@ void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems) 
 }
 
 template <typename Ops>
-static void launch_product(const DeviceHMatrix *D, const void *x_dev, void *y_dev, int numbering, hipStream_t st) {
+static void launch_product(DeviceHMatrix *D, const void *x_dev, void *y_dev, int numbering, hipStream_t st) {
     typedef typename Ops::T T;
     T *W = (T *)D->W;
     const int Ns = D->n_source;
+    hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
+    HIP_OK(hipEventRecord(ev[0], st));
     if (numbering == 0) {
         if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, D->perm_s, W, Ns);
     } else {
         HIP_OK(hipMemcpyAsync(W, x_dev, (size_t)Ns * sizeof(T), hipMemcpyDeviceToDevice, st));
     }
+    HIP_OK(hipEventRecord(ev[1], st));
     if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W);
+    HIP_OK(hipEventRecord(ev[2], st));
     if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W);
+    HIP_OK(hipEventRecord(ev[3], st));
     if (D->nB) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev);
+    HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
+    D->nprod++;
 }
 
 void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream) {
@@ -575,10 +581,8 @@ void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int 
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
-    HIP_OK(hipEventRecord(D->ev0, st));
     if (D->is_complex) launch_product<CplxOps>(D, x_dev, y_dev, numbering, st);
     else launch_product<RealOps>(D, x_dev, y_dev, numbering, st);
-    HIP_OK(hipEventRecord(D->ev1, st));
 }
 
 void device_matvec_host(const HMatrix &H, const void *x, void *y) {
@@ -593,15 +597,39 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     device_matvec_device(H, D->x_tmp, D->y_tmp, whole ? 0 : 1, D->stream);
     HIP_OK(hipMemcpyAsync(y, D->y_tmp, (size_t)(whole ? D->n_target : D->row_size) * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, D->ev0, D->ev1) == hipSuccess) D->last_us = ms * 1e3;
+}
+
+// average duration (microseconds) of the four launches over the completed products still in the ring:
+// out[0] gather/copy of x, out[1] phase A, out[2] phase A2, out[3] phase B.  Returns the number averaged.
+int device_phase_times(const HMatrix &H, double *out4) {
+    DeviceHMatrix *D = H.dev;
+    for (int i = 0; i < 4; i++) out4[i] = 0;
+    if (!D) return 0;
+    (void)hipSetDevice(D->device);
+    int cnt = 0;
+    const long long lo = std::max<long long>(0, D->nprod - DeviceHMatrix::RING);
+    for (long long p = lo; p < D->nprod; p++) {
+        hipEvent_t *ev = D->pev[p % DeviceHMatrix::RING];
+        if (hipEventQuery(ev[4]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float ms[4];
+        bool ok = true;
+        for (int i = 0; i < 4; i++) if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) { ok = false; (void)hipGetLastError(); }
+        if (!ok) continue;
+        for (int i = 0; i < 4; i++) out4[i] += ms[i] * 1e3;
+        cnt++;
+    }
+    if (cnt) for (int i = 0; i < 4; i++) out4[i] /= cnt;
+    return cnt;
 }
 
 double device_last_product_us(const HMatrix &H) {
-    if (!H.dev) return -1;
+    DeviceHMatrix *D = H.dev;
+    if (!D || D->nprod == 0) return -1;
+    hipEvent_t *ev = D->pev[(D->nprod - 1) % DeviceHMatrix::RING];
     float ms = 0;
-    if (hipEventQuery(H.dev->ev1) == hipSuccess && hipEventElapsedTime(&ms, H.dev->ev0, H.dev->ev1) == hipSuccess) return ms * 1e3;
-    return H.dev->last_us;
+    if (hipEventQuery(ev[4]) == hipSuccess && hipEventElapsedTime(&ms, ev[0], ev[4]) == hipSuccess) return ms * 1e3;
+    (void)hipGetLastError();
+    return -1;
 }
 
 int64_t device_resident_bytes(const HMatrix &H) {
@@ -618,8 +646,7 @@ void device_free(DeviceHMatrix *D) {
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
                     (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord})
         if (p) (void)hipFree(p);
-    if (D->ev0) (void)hipEventDestroy(D->ev0);
-    if (D->ev1) (void)hipEventDestroy(D->ev1);
+    for (auto &slot : D->pev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
     if (D->stream) (void)hipStreamDestroy(D->stream);
     delete D;
 }
@@ -632,10 +659,10 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     // Re-pack is not possible (the arena is gone), so copy buffers and relocate pointers in the tables.
     DeviceHMatrix *D = new DeviceHMatrix(*S);
     dst.dev = D;
-    D->stream = nullptr; D->ev0 = D->ev1 = nullptr;
+    D->stream = nullptr;
+    D->nprod = 0;
     HIP_OK(hipStreamCreate(&D->stream));
-    HIP_OK(hipEventCreate(&D->ev0));
-    HIP_OK(hipEventCreate(&D->ev1));
+    for (auto &slot : D->pev) for (auto &e : slot) { e = nullptr; HIP_OK(hipEventCreate(&e)); }
     auto dup = [](const void *p, size_t bytes) -> void * {
         void *q = nullptr;
         HIP_OK(hipMalloc(&q, std::max<size_t>(bytes, 1)));

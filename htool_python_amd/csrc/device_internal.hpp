@@ -62,8 +62,11 @@ struct DeviceHMatrix {
     void *x_tmp = nullptr, *y_tmp = nullptr;
     int n_source = 0, n_target = 0, row_off = 0, row_size = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_us = -1;
+    // ring of HIP events bracketing the four launches of the most recent products (kernel durations
+    // measured on the stream the kernels run on; read back by htool_hmatrix_phase_times)
+    static constexpr int RING = 32;
+    hipEvent_t pev[RING][5] = {};
+    long long nprod = 0;
     size_t table_bytes = 0;
     // cluster-ordered coordinates (SoA x|y|z) of a native generator, kept for dense evaluation / ACA
     double *tcoord = nullptr, *scoord = nullptr;

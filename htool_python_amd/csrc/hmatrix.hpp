@@ -141,6 +141,7 @@ void device_clone(const HMatrix &src, HMatrix &dst);
 void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *B);
 int64_t device_resident_bytes(const HMatrix &H);
 double device_last_product_us(const HMatrix &H);
+int device_phase_times(const HMatrix &H, double *out4);
 void device_free(DeviceHMatrix *d);
 
 } // namespace hm

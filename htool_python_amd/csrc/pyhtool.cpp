@@ -459,6 +459,11 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 return d;
             })
         .def("last_product_us", [](const H &s) { return htool_hmatrix_last_product_us(s.h); })
+        .def("phase_times_us", [](const H &s) {
+                double t[4];
+                int n = htool_hmatrix_phase_times(s.h, t);
+                return py::make_tuple(n, std::vector<double>(t, t + 4));
+            })
         .def("matvec_device", [](const H &s, std::uintptr_t x_dev, std::uintptr_t y_dev, int numbering, std::uintptr_t stream) {
                 check(htool_hmatrix_matvec_device(s.h, (const void *)x_dev, (void *)y_dev, numbering, (void *)stream));
             }, "x_ptr"_a, "y_ptr"_a, "numbering"_a = 0, "stream"_a = 0)

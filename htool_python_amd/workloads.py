@@ -1,0 +1,26 @@
+"""Synthetic workloads of BASELINE.md section 2 (host-side helpers for examples and bench.py)."""
+import numpy as np
+
+
+def points_in_sphere(n, seed=0):
+    """N points uniform in the unit ball; same construction and draw order as the reference's
+    example/create_geometry.py:13-22 (u, theta, phi from numpy's global RNG after np.random.seed)."""
+    np.random.seed(seed)
+    u = np.random.rand(n)
+    theta = 2 * np.pi * np.random.rand(n)
+    phi = np.arccos(2 * np.random.rand(n) - 1)
+    r = np.cbrt(u)
+    return np.array([r * np.sin(theta) * np.cos(phi), r * np.sin(theta) * np.sin(phi), r * np.cos(theta)])
+
+
+def algorithmic_bytes(leaves, n_source, n_rows, elem_bytes):
+    """B = s [ sum_dense m n + sum_lowrank r (m + n) ] + s (N_src + N_tgt),
+    split per product phase: (phase A: V panels + x, phase B: U and dense panels + y)."""
+    L = np.asarray(leaves, dtype=np.int64)
+    dense = L[:, 4] < 0
+    d = int((L[dense, 1] * L[dense, 3]).sum())
+    ru = int((L[~dense, 4] * L[~dense, 1]).sum())
+    rv = int((L[~dense, 4] * L[~dense, 3]).sum())
+    phase_a = elem_bytes * (rv + n_source)
+    phase_b = elem_bytes * (d + ru + n_rows)
+    return {"total": phase_a + phase_b, "phase_a": phase_a, "phase_b": phase_b, "dense_elements": d, "u_elements": ru, "v_elements": rv}

@@ -155,6 +155,11 @@ int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap);
 void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8);
 /* time of the kernels of the last product in microseconds (HIP events), -1 if none */
 double htool_hmatrix_last_product_us(const htool_hmatrix *h);
+/* average duration in microseconds of the four launches of a product (HIP events recorded on the
+ * stream the kernels ran on) over the completed products of the last 32: out4[0] x gather/copy,
+ * out4[1] phase A (V panels), out4[2] phase A2 (partial sums), out4[3] phase B (U and dense panels).
+ * Returns how many products were averaged.  Call after synchronising the stream. */
+int htool_hmatrix_phase_times(const htool_hmatrix *h, double *out4);
 
 /* ---- distributed operator (distributed_operator/utility.hpp:25-32, distributed_operator.hpp:18-65) */
 /* communicator supplied by the host language (mpi4py stand-in; backed by torch.distributed/RCCL or gloo).
