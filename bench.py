@@ -28,12 +28,23 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; measured copy ceiling 6290)
 
 
+def pmc_traffic(args, n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
+    same command line (profiles/), or None when no pass exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_1m_laplace.json")
+    if not (os.path.exists(path) and n == 1_000_000 and args.kernel == "laplace" and args.eps == 1e-3 and args.eta == 10.0 and args.leaf == 100 and args.gpus == 1):
+        return None
+    with open(path) as f:
+        return json.load(f).get("tile_gemv_wide_hbm_bytes_per_launch")
+
+
 def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
     """CPU leaf loop (oracle, OpenMP) on a bounded random sample of this operator's own leaves."""
     import numpy as np
 
     from oracle import oracle as O
 
+    O.set_num_threads(O.usable_cpus())
     rng = np.random.RandomState(0)
     L = np.asarray(leaves, dtype=np.int64)
     size = np.where(L[:, 4] < 0, L[:, 1] * L[:, 3], L[:, 4] * (L[:, 1] + L[:, 3])) * elem_bytes
@@ -226,7 +237,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": (ab["phase_b"] / t_b / 1e9 / HBM_PEAK_GBPS) if t_b else None,
-            "traffic": None,
+            "traffic": pmc_traffic(args, n),
             "launch_us": ph[3] if n_ph else None,
             "algorithmic_bytes_per_launch": ab["phase_b"],
             "launches_averaged": n_ph,

@@ -307,6 +307,43 @@ int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering
     API_END
 }
 
+int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
+                            int target_partition_number, int64_t *n_admissible, int64_t *n_dense, int *admissible4, int *dense4) {
+    API_BEGIN
+    HM_CHECK(target_root && source_root && params, "htool_block_tree_queues: null argument");
+    ClusterTree *T = CH(target_root)->tree, *S = CH(source_root)->tree;
+    BuildParams P;
+    P.eta = params->eta;
+    P.symmetry = params->symmetry;
+    P.uplo = params->uplo;
+    P.min_target_depth = params->minimal_target_depth;
+    P.min_source_depth = params->minimal_source_depth;
+    int t_root = 0;
+    if (target_partition_number >= 0) {
+        HM_CHECK(target_partition_number < (int)T->part_nodes.size(), "target_partition_number out of range");
+        t_root = T->part_nodes[target_partition_number];
+    }
+    std::vector<BlockRec> adm, dns;
+    build_block_tree(*T, *S, P, t_root, -1, adm, dns);
+    if (n_admissible) *n_admissible = (int64_t)adm.size();
+    if (n_dense) *n_dense = (int64_t)dns.size();
+    auto fill = [](const std::vector<BlockRec> &v, int *out) {
+        if (!out) return;
+        for (size_t i = 0; i < v.size(); i++) { out[4 * i] = v[i].t_off; out[4 * i + 1] = v[i].m; out[4 * i + 2] = v[i].s_off; out[4 * i + 3] = v[i].n; }
+    };
+    fill(adm, admissible4);
+    fill(dns, dense4);
+    API_END
+}
+int htool_cluster_tiles(const htool_cluster *root, int partition_number, int tile_max, int *out2, int cap) {
+    const ClusterTree &T = *CH(root)->tree;
+    int node = 0;
+    if (partition_number >= 0 && partition_number < (int)T.part_nodes.size()) node = T.part_nodes[partition_number];
+    TileSet ts = make_tiles(T, node, tile_max);
+    for (int i = 0; i < ts.count() && i < cap && out2; i++) { out2[2 * i] = ts.off[i]; out2[2 * i + 1] = ts.size[i]; }
+    return ts.count();
+}
+
 int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.blocks.size(); }
 void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5) {
     for (size_t i = 0; i < h->H.blocks.size(); i++) {

@@ -567,6 +567,24 @@ PYBIND11_MODULE(Htool, m) {
         .def("set_maximal_leaf_size", [](CB &self, int s) { self.max_leaf = s; })
         .def("set_partitioning_strategy", [](CB &self, std::shared_ptr<PyPartitioning> p) { self.strategy = p->strategy; });
 
+    // host-only introspection (no GPU needed): block-tree work queues and tile partition
+    m.def("block_tree_queues", [](const PyCluster &t, const PyCluster &s, double eta, int min_target_depth, int min_source_depth, int target_partition_number) {
+            htool_build_params p;
+            htool_build_params_default(&p);
+            p.eta = eta; p.minimal_target_depth = min_target_depth; p.minimal_source_depth = min_source_depth;
+            int64_t na = 0, nd = 0;
+            check(htool_block_tree_queues(t.owner->root, s.owner->root, &p, target_partition_number, &na, &nd, nullptr, nullptr));
+            py::array_t<int> a({(py::ssize_t)na, (py::ssize_t)4}), d({(py::ssize_t)nd, (py::ssize_t)4});
+            check(htool_block_tree_queues(t.owner->root, s.owner->root, &p, target_partition_number, &na, &nd, a.mutable_data(), d.mutable_data()));
+            return py::make_tuple(a, d);
+        }, "target_cluster"_a, "source_cluster"_a, "eta"_a, "min_target_depth"_a = 0, "min_source_depth"_a = 0, "target_partition_number"_a = -1);
+    m.def("cluster_tiles", [](const PyCluster &c, int partition_number, int tile_max) {
+            int n = htool_cluster_tiles(c.owner->root, partition_number, tile_max, nullptr, 0);
+            py::array_t<int> out({(py::ssize_t)n, (py::ssize_t)2});
+            htool_cluster_tiles(c.owner->root, partition_number, tile_max, out.mutable_data(), n);
+            return out;
+        }, "cluster"_a, "partition_number"_a = -1, "tile_max"_a = 128);
+
     declare_coefficient_classes<double>(m, "", "IGenerator", "VirtualGenerator", "VirtualLowRankGenerator", "NativeGenerator");
     declare_coefficient_classes<std::complex<double>>(m, "Complex", "IComplexGenerator", "ComplexVirtualGenerator", "VirtualComplexLowRankGenerator", "ComplexNativeGenerator");
 }

@@ -138,6 +138,15 @@ int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void 
 /* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
 int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);
 
+/* host-only introspection (needs no GPU): the two work queues of the block cluster tree BEFORE the
+ * leaves are filled -- admissible (to be compressed) and inadmissible (dense) -- as 4 ints per entry
+ * {t_off, m, s_off, n}.  Call with NULL arrays to get the counts.  (hmatrix_tree_builder.hpp:36) */
+int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
+                            int target_partition_number, int64_t *n_admissible, int64_t *n_dense, int *admissible4, int *dense4);
+/* host-only: the row/column tiles the panels of an H-matrix on these clusters would be grouped by
+ * (tile_max rows at most; 2 ints per tile {offset, size}); returns the tile count */
+int htool_cluster_tiles(const htool_cluster *root, int partition_number, int tile_max, int *out2, int cap);
+
 /* flattened leaf list: 5 ints per leaf {t_off, m, s_off, n, rank}, rank -1 = dense
  * (matplotlib/hmatrix.hpp:13-24,65-67) */
 int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h);

@@ -621,6 +621,14 @@ void orc_leaf_loop(int is_complex, int n_leaves, const int *leaves, const int64_
     for (int t = 0; t < nth; t++) if (!priv[t].empty()) for (size_t i = 0; i < (size_t)Nt * es; i++) yp[i] += priv[t][i];
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads() {
 #ifdef _OPENMP
     return omp_get_max_threads();

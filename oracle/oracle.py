@@ -55,6 +55,7 @@ def lib():
         L.orc_hmat_matvec.argtypes = [vp, vp, vp]
         L.orc_hmat_to_dense.argtypes = [vp, vp]
         L.orc_leaf_loop.argtypes = [ci, ci, vp, vp, vp, ci, vp, vp]
+        L.orc_set_num_threads.argtypes = [ci]
         _lib = L
     return _lib
 
@@ -178,6 +179,23 @@ def leaf_loop(leaves, offs, panels, Nt, xp, is_complex=False):
     yp = np.zeros(Nt, dtype=dt)
     lib().orc_leaf_loop(int(is_complex), len(leaves), _ptr(leaves), _ptr(offs), _ptr(panels), Nt, _ptr(xp), _ptr(yp))
     return yp
+
+
+def usable_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup quota) -- a GPU box hands each
+    job a CPU share smaller than the machine."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 def num_threads():

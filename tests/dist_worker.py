@@ -1,0 +1,92 @@
+"""Worker of the multi-process tests (launched by torch.distributed.run, one process per rank).
+
+mode "cpu": communicator shim + partition logic on the gloo backend (no GPU, no compute calls).
+mode "gpu": the reference's distributed-operator assertions (tests/test_distributed_operator.py:74-103)
+            with every rank building and multiplying its row block on the GPU (ranks may share one GPU).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main(mode):
+    import mpi4py
+
+    import Htool
+    from oracle import oracle as O
+
+    comm = mpi4py.MPI.COMM_WORLD
+    rank, world = comm.Get_rank(), comm.Get_size()
+    assert world == int(os.environ["WORLD_SIZE"]) and rank == int(os.environ["RANK"])
+    assert comm.size == world and comm.rank == rank
+
+    # ---- communicator shim
+    assert comm.allreduce(rank + 1, op=mpi4py.MPI.SUM) == world * (world + 1) // 2
+    counts = [3 + p for p in range(world)]
+    displs = [sum(counts[:p]) for p in range(world)]
+    send = np.full(counts[rank], rank + 1, dtype=np.uint8)
+    recv = np.zeros(sum(counts), dtype=np.uint8)
+    comm._htool_allgatherv(send, recv, counts, displs)
+    assert recv.tolist() == [p + 1 for p in range(world) for _ in range(counts[p])]
+    assert comm.bcast({"a": rank} if rank == 0 else None, root=0) == {"a": 0}
+
+    # ---- partition logic (tests/test_cluster.py:33-34 with np = world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "distributed_400_d3.npz"))
+    T, S = g["target"], g["source200"]
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(10)
+    tcl = b.create_cluster_tree(T, 2, size_of_partition=world)
+    scl = b.create_cluster_tree(S, 2, size_of_partition=world)
+    local = tcl.get_cluster_on_partition(rank)
+    total = sum(tcl.get_cluster_on_partition(p).get_size() for p in range(world))
+    assert total == len(local.get_permutation()) == len(tcl.get_permutation()) == 400
+    assert comm.allreduce(local.get_size(), op=mpi4py.MPI.SUM) == 400
+    # every rank's work queues tile exactly its own rows x all columns
+    adm, dns = Htool.block_tree_queues(tcl, scl, 10.0, target_partition_number=rank)
+    cover = np.zeros((local.get_size(), 200), dtype=np.int32)
+    for t_off, m, s_off, n in list(np.asarray(adm)) + list(np.asarray(dns)):
+        cover[t_off - local.get_offset():t_off - local.get_offset() + m, s_off:s_off + n] += 1
+    assert cover.min() == 1 and cover.max() == 1
+
+    if mode == "gpu":
+        from tests.helpers import NumpyGenerator
+
+        assert Htool.device_count() > 0
+        for eps in (1e-3, 1e-6):
+            for native in (False, True):
+                gen = Htool.NativeGenerator("inv_delta", T, S, 0.1) if native else NumpyGenerator(T, S)
+                holder = Htool.DefaultApproximationBuilder(gen, tcl, scl, Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N"), comm)
+                op, local_h = holder.distributed_operator, holder.hmatrix
+                assert op.shape == (comm.allreduce(local_h.shape[0], op=mpi4py.MPI.SUM), local_h.shape[1]) == (400, 200)
+                print(local_h.get_distributed_information(comm) if rank == 0 else "", end="")
+                y = op * g["x200"]
+                assert np.linalg.norm(y - g["y200"]) / np.linalg.norm(g["y200"]) < eps
+                for mu in (5, 1):
+                    np.random.seed(1)
+                    X = np.asfortranarray(np.random.rand(200, mu))
+                    Y = op @ X
+                    Ye = O.dense_matvec(O.K_INV_DELTA, T, S, X, 0.1)
+                    assert Y.shape == (400, mu) and np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < eps
+                # every rank returns the same replicated result
+                ysum = comm.allreduce(y, op=mpi4py.MPI.SUM)
+                assert np.allclose(ysum, world * y, rtol=1e-13, atol=0)
+        # partitioned geometry of example/use_distributed_operator.py (local partition given), world == 2 only
+        if world == 2:
+            gp = np.load(os.path.join(ROOT, "tests", "golden", "partitioned_1000_w2.npz"))
+            tp = b.create_cluster_tree_from_local_partition(gp["target"], 2, 2, gp["partition"])
+            sp = b.create_cluster_tree(gp["source"], 2)
+            gen = NumpyGenerator(gp["target"], gp["source"])
+            holder = Htool.DefaultApproximationBuilder(gen, tp, sp, Htool.HMatrixTreeBuilder(1e-3, 10.0, "N", "N"), comm)
+            Htool.openmp_recompression(holder.hmatrix)
+            y = holder.distributed_operator * gp["x"]
+            assert np.linalg.norm(y - gp["y"]) / np.linalg.norm(gp["y"]) < 1e-3
+    comm.Barrier()
+    print(f"rank {rank}/{world} ok ({mode})", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

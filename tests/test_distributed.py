@@ -1,0 +1,41 @@
+"""Multi-process tests (one process per rank, as the reference runs its suite under mpirun -np k,
+.github/workflows/CI.yml:138-145).  CPU: gloo, world size 2 and 3.  GPU: two ranks sharing the box's GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, mode, timeout=600):
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "2"
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), mode]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    for p in range(world):
+        assert f"rank {p}/{world} ok" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_shim_and_partition_logic_gloo(built, oracle, world):
+    _launch(world, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_distributed_operator_gpu(built, oracle, world):
+    _launch(world, "gpu")

@@ -1,0 +1,224 @@
+"""CPU tests of the product's host logic (no GPU, no compute calls): cluster tree, block-tree work
+queues and tile partition through the C ABI / the Htool shim, against the oracle's restatement, plus
+the reference's cluster-tree invariants (tests/test_cluster.py:8-34)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol(built):
+    lib_path, _ = built
+    lib = ctypes.CDLL(lib_path)
+    header = open(os.path.join(ROOT, "include", "htool_mi355x.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(htool_[a-z0-9_]+)\s*\(", header))
+    names -= {"htool_log_sink", "htool_copy_submatrix_fn", "htool_compress_fn", "htool_dense_blocks_fn"}
+    assert len(names) > 40
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.htool_last_error.restype = ctypes.c_char_p
+    assert lib.htool_device_count() >= 0
+
+
+def test_no_gpu_means_loud_failure(built):
+    """The product path has no CPU fallback: without a device, build fails with a clear error."""
+    import Htool
+
+    if Htool.device_count() > 0:
+        pytest.skip("a GPU is present")
+    pts = np.random.RandomState(0).rand(3, 200)
+    b = Htool.ClusterTreeBuilder()
+    cl = b.create_cluster_tree(pts, 2)
+    gen = Htool.NativeGenerator("laplace", pts, pts)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Htool.HMatrixTreeBuilder(1e-3, 10.0, "N", "N").build(gen, cl, cl)
+
+
+def test_logger_routes_to_python_logging(built, caplog):
+    """tests/test_logger.py:6-8 + src/htool/misc/logger.hpp:13-33."""
+    import logging
+
+    import Htool
+
+    with caplog.at_level(logging.DEBUG, logger="Htool"):
+        Htool.test_logger()
+    got = [(r.levelname, r.getMessage()) for r in caplog.records if r.name == "Htool"]
+    assert got == [("CRITICAL", "Critical message"), ("ERROR", "Error message"), ("WARNING", "Warning message"),
+                   ("DEBUG", "Debug message"), ("INFO", "Info message")]
+
+
+def _make_cluster(points, children, partition_type, world, max_leaf=10, strategy=None):
+    import Htool
+
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(max_leaf)
+    if strategy is not None:
+        b.set_partitioning_strategy(strategy)
+    n = points.shape[1]
+    if partition_type == "None":
+        return b.create_cluster_tree(points, children, size_of_partition=world), None, False
+    local = n // world
+    part = np.zeros((2, world), dtype=int)
+    for i in range(world):
+        part[0, i] = i * local
+        part[1, i] = local if i < world - 1 else n - (world - 1) * local
+    if partition_type == "Local":
+        return b.create_cluster_tree_from_local_partition(points, children, world, part), part, True
+    glob = np.zeros(n)  # float labels, force-cast by the binding (tests/conftest.py:173-178)
+    for i in range(world):
+        glob[part[0, i]:part[0, i] + part[1, i]] = i
+    return b.create_cluster_tree_from_global_partition(points, children, world, glob), glob.astype(np.int32), False
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("dimension,partition_type,children", [
+    (2, "None", 2), (3, "None", 2), (2, "Local", 2), (3, "Local", 2), (2, "Global", 2), (3, "Global", 2),
+    (2, "None", 3), (2, "None", 9), (2, "None", 10),
+])
+def test_cluster_tree_invariants_and_oracle_equality(built, oracle, dimension, partition_type, children, world):
+    """Reference invariants (tests/test_cluster.py:33-34) for every 'rank count' it is run with
+    (mpirun -np 1..4), and node-for-node equality with the oracle's tree."""
+    O = oracle
+    rng = np.random.RandomState(0)
+    n = 500
+    pts = rng.rand(dimension, n)
+    if partition_type != "None":
+        local = n // world
+        for i in range(world):
+            pts[0, i * local:(i + 1) * local if i < world - 1 else n] = i  # tests/conftest.py:111-129
+    cl, part, is_local = _make_cluster(pts, children, partition_type, world)
+    perm = np.asarray(cl.get_permutation())
+    assert sorted(perm.tolist()) == list(range(n))
+    total = sum(cl.get_cluster_on_partition(p).get_size() for p in range(world))
+    assert total == len(perm) == len(np.asarray(cl.get_cluster_on_partition(0).get_permutation()))
+    offs = [cl.get_cluster_on_partition(p).get_offset() for p in range(world)]
+    assert offs == sorted(offs) and offs[0] == 0
+    assert cl.get_maximal_leaf_size() == 10
+    if partition_type != "None":
+        for p in range(world):
+            sub = cl.get_cluster_on_partition(p)
+            idx = perm[sub.get_offset():sub.get_offset() + sub.get_size()]
+            assert np.all(pts[0, idx] == p)
+    # oracle equality
+    oc = O.Cluster(pts, n_children=children, size_of_partition=world, partition=part, partition_is_local=is_local, max_leaf=10)
+    assert np.array_equal(oc.perm, perm)
+    ints, dbl = cl._nodes()
+    mine = {(r[0], r[1]): (r[2], r[5], r[6]) for r in ints}
+    theirs = {(r[0], r[1]): (r[2], r[5], r[6]) for r in oc.inodes}
+    assert mine == theirs
+    geo_m = {(r[0], r[1]): tuple(d) for r, d in zip(ints, dbl)}
+    geo_o = {(r[0], r[1]): tuple(d) for r, d in zip(oc.inodes, oc.dnodes)}
+    for k in geo_m:
+        assert np.allclose(geo_m[k], geo_o[k], rtol=1e-14, atol=1e-15)
+    # leaves respect the minimum cluster size; parents are the union of their children
+    for r in ints:
+        if r[5] > 0:
+            ch = ints[r[4]:r[4] + r[5]]
+            assert ch[0, 0] == r[0] and ch[:, 1].sum() == r[1] and np.all(ch[:, 1] >= 10)
+
+
+@pytest.mark.parametrize("strategy_name", ["PCARegular", "PCAGeometric", "BoundingBoxRegular", "BoundingBoxGeometric"])
+def test_partitioning_strategies(built, oracle, strategy_name):
+    import Htool
+
+    O = oracle
+    pts = np.random.RandomState(1).rand(3, 800) * np.array([[4.0], [1.0], [0.5]])
+    cl, _, _ = _make_cluster(pts, 2, "None", 2, strategy=getattr(Htool, strategy_name)())
+    sid = {"PCARegular": 0, "PCAGeometric": 1, "BoundingBoxRegular": 2, "BoundingBoxGeometric": 3}[strategy_name]
+    oc = O.Cluster(pts, size_of_partition=2, strategy=sid)
+    assert np.array_equal(oc.perm, np.asarray(cl.get_permutation()))
+    assert sorted(np.asarray(cl.get_permutation()).tolist()) == list(range(800))
+
+
+def test_radii_and_weights(built, oracle):
+    import Htool
+
+    rng = np.random.RandomState(2)
+    pts, radii, weights = rng.rand(3, 300), rng.rand(300) * 0.1, rng.rand(300) + 0.5
+    b = Htool.ClusterTreeBuilder()
+    cl = b.create_cluster_tree(pts, 2, radii=radii, weights=weights)
+    oc = oracle.Cluster(pts, size_of_partition=2, radii=radii, weights=weights)
+    assert np.array_equal(oc.perm, np.asarray(cl.get_permutation()))
+    ints, dbl = cl._nodes()
+    assert np.isclose(dbl[0, 3], oc.dnodes[0, 3])
+
+
+def test_wrong_partition_format_raises(built):
+    import Htool
+
+    pts = np.random.RandomState(0).rand(2, 100)
+    b = Htool.ClusterTreeBuilder()
+    with pytest.raises(RuntimeError, match="Wrong format for partition"):
+        b.create_cluster_tree_from_global_partition(pts, 2, 2, np.zeros(99))
+    with pytest.raises(RuntimeError, match="Wrong format for partition"):
+        b.create_cluster_tree_from_local_partition(pts, 2, 2, np.zeros((3, 2)))
+
+
+@pytest.mark.parametrize("eta", [0.5, 10.0, 100.0])
+@pytest.mark.parametrize("case", ["square", "rect", "partition"])
+def test_block_tree_queues_equal_oracle_and_tile_the_matrix(built, oracle, eta, case):
+    """The two work queues cover every matrix entry exactly once, every admissible
+    block satisfies the admissibility inequality, and both queues equal the oracle's."""
+    import Htool
+
+    O = oracle
+    rng = np.random.RandomState(3)
+    T = rng.rand(3, 700)
+    S = T if case != "rect" else rng.rand(3, 450) + 0.3
+    world = 2 if case == "partition" else 1
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(10)
+    tcl = b.create_cluster_tree(T, 2, size_of_partition=world)
+    scl = tcl if S is T else b.create_cluster_tree(S, 2, size_of_partition=world)
+    otc = O.Cluster(T, size_of_partition=world, max_leaf=10)
+    osc = otc if S is T else O.Cluster(S, size_of_partition=world, max_leaf=10)
+    for p in ([-1] if world == 1 else [0, 1]):
+        adm, dns = Htool.block_tree_queues(tcl, scl, eta, target_partition_number=p)
+        oadm, odns = O.blocktree(otc, osc, eta, target_partition=p)
+        key = lambda tree, ids: sorted((tree.inodes[i, 0], tree.inodes[i, 1]) for i in ids)  # noqa: E731
+        to_set = lambda q: sorted(map(tuple, np.asarray(q)))  # noqa: E731
+        o_adm = sorted((otc.inodes[t, 0], otc.inodes[t, 1], osc.inodes[s, 0], osc.inodes[s, 1]) for t, s in oadm)
+        o_dns = sorted((otc.inodes[t, 0], otc.inodes[t, 1], osc.inodes[s, 0], osc.inodes[s, 1]) for t, s in odns)
+        assert to_set(adm) == o_adm and to_set(dns) == o_dns
+        sub = tcl.get_cluster_on_partition(p) if p >= 0 else tcl
+        r0, nr = sub.get_offset(), sub.get_size()
+        cover = np.zeros((nr, S.shape[1]), dtype=np.int32)
+        for t_off, m, s_off, n in list(np.asarray(adm)) + list(np.asarray(dns)):
+            cover[t_off - r0:t_off - r0 + m, s_off:s_off + n] += 1
+        assert cover.min() == 1 and cover.max() == 1
+        # admissibility of every low-rank candidate, from the node geometry
+        ints, dbl = tcl._nodes()
+        sints, sdbl = scl._nodes()
+        gt = {(r[0], r[1]): d for r, d in zip(ints, dbl)}
+        gs = {(r[0], r[1]): d for r, d in zip(sints, sdbl)}
+        for t_off, m, s_off, n in np.asarray(adm):
+            a, c = gt[(t_off, m)], gs[(s_off, n)]
+            dist = np.linalg.norm(a[:3] - c[:3]) - a[3] - c[3]
+            assert 2 * min(a[3], c[3]) < eta * max(0.0, dist)
+
+
+@pytest.mark.parametrize("tile_max", [16, 64, 128])
+def test_tiles_partition_rows_and_align_with_clusters(built, tile_max):
+    """Row/column tiles (pieces of cluster leaves, <= tile_max) partition the index range, and every
+    cluster node is a union of whole tiles -- the property the tile-major panel layout relies on."""
+    import Htool
+
+    pts = np.random.RandomState(4).rand(3, 3000)
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(40)
+    cl = b.create_cluster_tree(pts, 2, size_of_partition=3)
+    tiles = np.asarray(Htool.cluster_tiles(cl, -1, tile_max))
+    assert tiles[0, 0] == 0 and np.all(tiles[1:, 0] == tiles[:-1, 0] + tiles[:-1, 1]) and tiles[-1].sum() == 3000
+    assert tiles[:, 1].max() <= tile_max and tiles[:, 1].min() >= 1
+    starts = set(tiles[:, 0].tolist()) | {3000}
+    ints, _ = cl._nodes()
+    for r in ints:
+        assert r[0] in starts and r[0] + r[1] in starts
+    sub = np.asarray(Htool.cluster_tiles(cl, 1, tile_max))
+    p1 = cl.get_cluster_on_partition(1)
+    assert sub[0, 0] == p1.get_offset() and sub[:, 1].sum() == p1.get_size()
