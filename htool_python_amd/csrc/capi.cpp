@@ -276,8 +276,8 @@ int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, 
 }
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream) {
     API_BEGIN
-    HM_CHECK(numbering == 0 || numbering == 1, "numbering must be 0 (user) or 1 (cluster)");
-    HM_CHECK(numbering == 1 || h->H.t_root == 0, "user numbering needs an H-matrix built on the whole target cluster");
+    HM_CHECK(numbering >= 0 && numbering <= 2, "numbering must be 0 (user), 1 (cluster) or 2 (user in, cluster out)");
+    HM_CHECK(numbering != 0 || h->H.t_root == 0, "user-numbered output needs an H-matrix built on the whole target cluster");
     device_matvec_device(h->H, x_dev, y_dev, numbering, stream);
     API_END
 }

@@ -391,7 +391,9 @@ struct DeviceBuilder {
     void pack_batch(const std::vector<int64_t> &batch_blocks, const void *d_arena, bool eval_dense) {
         BatchLayout L;
         L.batch_id = (int)D->batches.size();
+        double tl0 = wall_seconds();
         compute_batch_layout(H, batch_blocks, vec_rows, L);
+        double tl1 = wall_seconds();
         for (int64_t bi : batch_blocks) H.blocks[bi].batch = L.batch_id;
         DevBatch B;
         size_t szB = std::max<int64_t>(L.panelB_elems, 1) * sizeof(T), szA = std::max<int64_t>(L.panelA_elems, 1) * sizeof(T);
@@ -420,7 +422,9 @@ struct DeviceBuilder {
         a.tile_pbase = d_ap; a.tile_ibase = d_ao; a.panel = B.panelA; a.index = B.oidxA;
         if (!L.v_item_block.empty()) hipLaunchKernelGGL(pack_v_kernel<T>, dim3((unsigned)L.v_item_block.size()), dim3(256), 0, D->stream, a);
         HIP_OK(hipGetLastError());
+        double tl2 = wall_seconds();
         HIP_OK(hipStreamSynchronize(D->stream));
+        log_message(LOG_DEBUG, strprintf("pack batch %d: layout %.3f s, alloc+upload %.3f s, kernels %.3f s, panels %.2f GB", L.batch_id, tl1 - tl0, tl2 - tl1, wall_seconds() - tl2, (szA + szB) / 1e9));
         for (void *p : {(void *)d_blocks, (void *)d_ub, (void *)d_ut, (void *)d_vb, (void *)d_vt, (void *)d_bn, (void *)d_an, (void *)d_bp, (void *)d_bc, (void *)d_ap, (void *)d_ao}) (void)hipFree(p);
         D->batches.push_back(B);
         BatchTables bt;
@@ -560,7 +564,7 @@ static void launch_product(DeviceHMatrix *D, const void *x_dev, void *y_dev, int
     const int Ns = D->n_source;
     hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
     HIP_OK(hipEventRecord(ev[0], st));
-    if (numbering == 0) {
+    if (numbering == 0 || numbering == 2) {
         if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, D->perm_s, W, Ns);
     } else {
         HIP_OK(hipMemcpyAsync(W, x_dev, (size_t)Ns * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -594,7 +598,7 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     // a matrix built on the whole target cluster answers in user numbering; one built on a partition
     // answers with its local rows in cluster order
     const bool whole = H.t_root == 0;
-    device_matvec_device(H, D->x_tmp, D->y_tmp, whole ? 0 : 1, D->stream);
+    device_matvec_device(H, D->x_tmp, D->y_tmp, whole ? 0 : 2, D->stream);
     HIP_OK(hipMemcpyAsync(y, D->y_tmp, (size_t)(whole ? D->n_target : D->row_size) * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
 }

@@ -131,8 +131,9 @@ int htool_hmatrix_matvec(const htool_hmatrix *h, char trans, const void *alpha, 
 /* Y = alpha H X + beta Y, X column-major n_cols x mu; replaces add_hmatrix_matrix_product (hmatrix.hpp:134) */
 int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, const void *X, int mu, const void *beta, void *Y);
 /* device-pointer variants for GPU-resident loops (Krylov, distributed bench): y = H x with
- * x (n_cols) and y (rows of this H-matrix) device buffers.  numbering: 0 = user, 1 = cluster
- * (cluster: x is the whole permuted source vector, y the local row slice).  stream = hipStream_t. */
+ * x (n_cols) and y (rows of this H-matrix) device buffers.  numbering: 0 = user in and out,
+ * 1 = cluster in and out (x is the whole permuted source vector, y the local row slice),
+ * 2 = user in, cluster (local row slice) out.  stream = hipStream_t. */
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream);
 
 /* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
