@@ -91,13 +91,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000, help="number of points")
+    ap.add_argument("--points", dest="n", type=int, default=1_000_000, help="number of points")
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--eta", type=float, default=10.0)
     ap.add_argument("--leaf", type=int, default=100, help="maximal_leaf_size of the cluster tree")
     ap.add_argument("--kernel", default="laplace", choices=["laplace", "inv_delta", "helmholtz"])
     ap.add_argument("--kappa", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) is the measured path; gloo stages the exchange through the host so that the "
+                         "multi-rank logic can be rehearsed with several ranks on ONE GPU (not a benchmark)")
     ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
     args = ap.parse_args()
 
@@ -109,12 +112,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if args.backend == "gloo":  # rehearsal: ranks may share a GPU
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import Htool
     from htool_python_amd.workloads import algorithmic_bytes, points_in_sphere
@@ -171,9 +179,14 @@ def main():
         equal = len(set(sizes)) == 1
         parts = None if equal else list(torch.split(x_full, sizes))
 
+        host_parts = [torch.empty(sz, dtype=dtype) for sz in sizes]
+
         def step():
             # exchange: every GPU contributes its slice of x (cluster numbering), RCCL over xGMI
-            if equal:
+            if args.backend == "gloo":
+                dist.all_gather(host_parts, x_local.cpu())
+                x_full.copy_(torch.cat(host_parts))
+            elif equal:
                 dist.all_gather_into_tensor(x_full, x_local)
             else:
                 dist.all_gather(parts, x_local)
@@ -196,8 +209,24 @@ def main():
     n_ph, ph = H.phase_times_us()
 
     tot_bytes = float(ab["total"])
+    if args.check and world > 1:
+        # distributed result vs exact rows: gather y slices and x slices on every rank
+        ys = [torch.empty(sz, dtype=dtype) for sz in sizes]
+        xs = [torch.empty(sz, dtype=dtype) for sz in sizes]
+        if args.backend == "gloo":
+            dist.all_gather(ys, y.cpu())
+            dist.all_gather(xs, x_local.cpu())
+        else:
+            ysd, xsd = [t.cuda() for t in ys], [t.cuda() for t in xs]
+            dist.all_gather(ysd, y)
+            dist.all_gather(xsd, x_local)
+            ys, xs = [t.cpu() for t in ysd], [t.cpu() for t in xsd]
+        perm = np.asarray(cluster.get_permutation())
+        y_user, x_user = np.zeros(n, dtype=ys[0].numpy().dtype), np.zeros(n, dtype=ys[0].numpy().dtype)
+        y_user[perm] = torch.cat(ys).numpy()
+        x_user[perm] = torch.cat(xs).numpy()
     if world > 1:
-        t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -218,6 +247,7 @@ def main():
         "vs_baseline": None,
         "dtype": "c128" if is_complex else "f64",
         "data": "synthetic",
+        "backend": ("rccl" if args.backend == "nccl" else "gloo-host-staged (rehearsal, not a benchmark)") if world > 1 else None,
         "config": {
             "workload": f"{n}-point 3D {args.kernel} H-matrix matvec (BASELINE configs[3] operator{' on one GPU' if world == 1 else ', row-cluster split'}), "
                         f"eta={args.eta:g}, eps={args.eps:g}, leaf={args.leaf}, ACA on device, points seed 0 unit ball",
@@ -246,13 +276,13 @@ def main():
         }
         out["hmatrix"] = {"n_dense": stats["n_dense"], "n_low_rank": stats["n_low_rank"], "max_rank": stats["max_rank"],
                           "mean_rank": stats["sum_rank"] / max(stats["n_low_rank"], 1), "hbm_resident_GB": stats["hbm_bytes"] / 1e9}
-        if args.check and world == 1:
+        if args.check:
             from oracle import oracle as O
 
             rows = np.arange(0, n, max(1, n // 256))
-            ye = O.dense_matvec({"laplace": 1, "inv_delta": 0, "helmholtz": 2}[args.kernel], pts, pts, x.cpu().numpy(), param, rows=rows)
-            yy = y.cpu().numpy()[rows]
-            out["rel_err_sampled_rows"] = float(np.linalg.norm(yy - ye) / np.linalg.norm(ye))
+            xx, yy = (x.cpu().numpy(), y.cpu().numpy()) if world == 1 else (x_user, y_user)
+            ye = O.dense_matvec({"laplace": 1, "inv_delta": 0, "helmholtz": 2}[args.kernel], pts, pts, xx, param, rows=rows)
+            out["rel_err_sampled_rows"] = float(np.linalg.norm(yy[rows] - ye) / np.linalg.norm(ye))
         if world == 1 and not args.no_cpu_baseline and not is_complex:
             out["cpu_baseline"] = cpu_baseline(H, leaves, n, n, elem)
         print(json.dumps(out), flush=True)
