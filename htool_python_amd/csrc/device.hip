@@ -163,6 +163,20 @@ __global__ void gather_x_kernel(const T *__restrict__ x, const int *__restrict__
     if (i < n) W[i] = x[perm[i]];
 }
 
+// y[map(i)] = sum_s ypart[s][i], slices added in order (deterministic); map = perm (user numbering) or identity
+template <typename T>
+__global__ void reduce_y_kernel(const T *__restrict__ ypart, long long stride, int nslices, int n, const int *__restrict__ perm, T *__restrict__ y) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T acc = ypart[i];
+    for (int s = 1; s < nslices; s++) {
+        T v = ypart[(long long)s * stride + i];
+        if constexpr (sizeof(T) == 8) acc = acc + v;
+        else { acc.x += v.x; acc.y += v.y; }
+    }
+    y[perm ? perm[i] : i] = acc;
+}
+
 template <typename T>
 __global__ void set_one_kernel(T *W, long long idx, T one) { W[idx] = one; }
 
@@ -491,6 +505,11 @@ struct DeviceBuilder {
             tBc.push_back(tc);
             wB.push_back(work);
         }
+        const int target_items = 256 * 16; // workgroups wanted per launch (256 CUs)
+        long long total_chunks = 0;
+        for (size_t b = 0; b < tabs.size(); b++)
+            for (int c = 0; c < nct; c++) total_chunks += (tabs[b].a_nrows[c] + TM - 1) / TM;
+        const int qmax = (int)std::max<long long>(4, ((total_chunks + target_items - 1) / target_items + 3) / 4 * 4);
         for (size_t b = 0; b < tabs.size(); b++)
             for (int c = 0; c < nct; c++) {
                 int nr = tabs[b].a_nrows[c];
@@ -501,12 +520,20 @@ struct DeviceBuilder {
                 s.cidx = D->iota + H.ctiles.off[c];
                 s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.pad_ = 0;
                 s.chunk_stride = (long long)H.ctiles.size[c] * TM;
-                GTile t;
-                t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = nr;
-                t.omap = D->batches[b].oidxA + tabs[b].a_obase[c]; t.out_begin = 0;
-                segs.push_back(s);
-                tA.push_back(t);
-                wA.push_back((double)nr * s.ncols);
+                // cut tall tiles into pieces of at most qmax row chunks (independent outputs, no reduction)
+                for (int q0 = 0; q0 < nq; q0 += qmax) {
+                    const int q1 = std::min(nq, q0 + qmax);
+                    GSeg sp = s;
+                    sp.panel = (const char *)s.panel + (size_t)q0 * (size_t)s.chunk_stride * sizeof(T);
+                    if (q1 < nq) sp.ld_last = TM;
+                    GTile t;
+                    t.seg_begin = (long long)segs.size(); t.nseg = 1;
+                    t.nrows = (q1 < nq ? q1 * TM : nr) - q0 * TM;
+                    t.omap = D->batches[b].oidxA + tabs[b].a_obase[c] + (long long)q0 * TM; t.out_begin = 0;
+                    segs.push_back(sp);
+                    tA.push_back(t);
+                    wA.push_back((double)t.nrows * s.ncols);
+                }
             }
         for (size_t b = 0; b < tabs.size(); b++)
             for (auto &r : tabs[b].reduces) {
@@ -528,6 +555,50 @@ struct DeviceBuilder {
             t.swap(o);
             if (twin) twin->swap(o2);
         };
+        // phase B column slices for small operators
+        std::vector<GTile> tBs;
+        std::vector<double> wBs;
+        D->splitB = std::max(1, std::min(8, (target_items + std::max(nrt, 1) - 1) / std::max(nrt, 1)));
+        if (D->splitB > 1) {
+            const int S = D->splitB;
+            D->ypart_stride = ((long long)H.row_size + 1) / 2 * 2;
+            HIP_OK(hipMalloc(&D->ypart, (size_t)S * D->ypart_stride * sizeof(T)));
+            D->table_bytes += (size_t)S * D->ypart_stride * sizeof(T);
+            for (int r = 0; r < nrt; r++) {
+                const GTile &t0 = tBc[r];
+                long long C = 0;
+                for (int q = 0; q < t0.nseg; q++) C += segs[t0.seg_begin + q].ncols;
+                // slice boundaries in units of 16 columns (the kernel's unrolled chunk)
+                const long long per = ((C + S - 1) / S + 15) / 16 * 16;
+                for (int sl = 0; sl < S; sl++) {
+                    const long long lo = std::min<long long>(C, sl * per), hi = std::min<long long>(C, (sl + 1) * per);
+                    GTile t = t0;
+                    t.seg_begin = (long long)segs.size();
+                    t.nseg = 0;
+                    t.omap = nullptr;
+                    t.out_begin = (long long)sl * D->ypart_stride + (H.rtiles.off[r] - H.row_off);
+                    long long pos = 0;
+                    double work = 0;
+                    for (int q = 0; q < t0.nseg; q++) {
+                        const GSeg sg = segs[t0.seg_begin + q];
+                        const long long a = std::max(lo, pos), bnd = std::min(hi, pos + sg.ncols);
+                        if (a < bnd) {
+                            GSeg sp = sg;
+                            sp.panel = (const char *)sg.panel + (size_t)(a - pos) * (size_t)sg.ld_last * sizeof(T);
+                            sp.cidx = sg.cidx + (a - pos);
+                            sp.ncols = (int)(bnd - a);
+                            segs.push_back(sp);
+                            t.nseg++;
+                            work += (double)sp.ncols * sg.ld_last;
+                        }
+                        pos += sg.ncols;
+                    }
+                    tBs.push_back(t);
+                    wBs.push_back(work);
+                }
+            }
+            sort_heavy(tBs, wBs, nullptr);
+        }
         sort_heavy(tB, wB, &tBc);
         sort_heavy(tA, wA, nullptr);
         sort_heavy(tA2, wA2, nullptr);
@@ -536,6 +607,8 @@ struct DeviceBuilder {
         D->tilesB_cluster = upload(tBc, &D->table_bytes);
         D->tilesA = upload(tA, &D->table_bytes);
         D->tilesA2 = upload(tA2, &D->table_bytes);
+        D->tilesB_split = upload(tBs, &D->table_bytes);
+        D->nB_split = (int)tBs.size();
         D->nB = (int)tB.size(); D->nA = (int)tA.size(); D->nA2 = (int)tA2.size();
     }
 };
@@ -574,7 +647,11 @@ static void launch_product(DeviceHMatrix *D, const void *x_dev, void *y_dev, int
     HIP_OK(hipEventRecord(ev[2], st));
     if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W);
     HIP_OK(hipEventRecord(ev[3], st));
-    if (D->nB) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev);
+    if (D->splitB > 1 && D->nB_split) {
+        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, (T *)D->ypart);
+        hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
+                           numbering == 0 ? D->perm_t + D->row_off : nullptr, (T *)y_dev);
+    } else if (D->nB) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev);
     HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
     D->nprod++;
@@ -648,7 +725,7 @@ void device_free(DeviceHMatrix *D) {
     (void)hipSetDevice(D->device);
     for (auto &B : D->batches) { (void)hipFree(B.panelB); (void)hipFree(B.panelA); (void)hipFree(B.cidxB); (void)hipFree(B.oidxA); }
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
-                    (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord})
+                    (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord, (void *)D->tilesB_split, D->ypart})
         if (p) (void)hipFree(p);
     for (auto &slot : D->pev) for (auto &e : slot) if (e) (void)hipEventDestroy(e);
     if (D->stream) (void)hipStreamDestroy(D->stream);
@@ -722,6 +799,8 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     fix_tiles(S->tilesB_cluster, S->nB, &D->tilesB_cluster);
     fix_tiles(S->tilesA, S->nA, &D->tilesA);
     fix_tiles(S->tilesA2, S->nA2, &D->tilesA2);
+    fix_tiles(S->tilesB_split, S->nB_split, &D->tilesB_split);
+    if (S->ypart) D->ypart = dup_alloc(S->ypart);
     segs.resize((size_t)nseg_used);
     for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); }
     D->segs = upload(segs);

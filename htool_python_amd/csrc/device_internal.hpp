@@ -56,6 +56,12 @@ struct DeviceHMatrix {
     GSeg *segs = nullptr;
     GTile *tilesB_user = nullptr, *tilesB_cluster = nullptr, *tilesA = nullptr, *tilesA2 = nullptr;
     int nB = 0, nA = 0, nA2 = 0;
+    // small operators: every row tile is cut in splitB column slices (more, smaller workgroups); the slices
+    // write partial sums to ypart[slice][row] and reduce_y_kernel adds them in slice order
+    int splitB = 1, nB_split = 0;
+    GTile *tilesB_split = nullptr;
+    void *ypart = nullptr;
+    long long ypart_stride = 0;
     int *perm_s = nullptr, *perm_t = nullptr, *iota = nullptr, *ones_idx = nullptr;
     void *W = nullptr;
     long long W_elems = 0;
