@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the measured path; gloo stages the exchange through the host so that the "
                          "multi-rank logic can be rehearsed with several ranks on ONE GPU (not a benchmark)")
+    ap.add_argument("--rhs", type=int, default=1, help="right-hand sides per step (H @ X, one sweep of the panels per 8 columns); 1 = the headline matvec")
     ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
     args = ap.parse_args()
 
@@ -125,9 +126,12 @@ def main():
             dist.init_process_group(backend="gloo")
 
     import Htool
-    from htool_python_amd.workloads import algorithmic_bytes, points_in_sphere
+    from htool_python_amd.workloads import algorithmic_bytes, points_in_sphere, usable_cpus
 
     Htool.set_device(local_rank)
+    # host threads for the cluster-tree construction: this rank's share of the CPUs (torchrun exports
+    # OMP_NUM_THREADS=1 for multi-rank launches, and a node-wide default would oversubscribe 8 ranks)
+    Htool.set_num_threads(max(1, min(16, usable_cpus() // world)))
     is_complex = args.kernel == "helmholtz"
     elem = 16 if is_complex else 8
     dtype = torch.complex128 if is_complex else torch.float64
@@ -165,8 +169,15 @@ def main():
         x = x.cuda()
         y = torch.zeros(n, dtype=dtype, device="cuda")
 
+        if args.rhs > 1:
+            x = torch.rand(args.rhs, n, dtype=torch.float64, generator=gen_t).to(dtype).cuda()
+            y = torch.zeros(args.rhs, n, dtype=dtype, device="cuda")
+
         def step():
-            H.matvec_device(x.data_ptr(), y.data_ptr(), 0, stream)
+            if args.rhs > 1:
+                H.matmat_device(x.data_ptr(), n, y.data_ptr(), n, args.rhs, 0, stream)
+            else:
+                H.matvec_device(x.data_ptr(), y.data_ptr(), 0, stream)
     else:
         local = cluster.get_cluster_on_partition(rank)
         sizes = [cluster.get_cluster_on_partition(p).get_size() for p in range(world)]
@@ -257,6 +268,7 @@ def main():
         "build_s": t_build,
         "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,
+        "rhs_per_step": args.rhs,
     }
     if rank == 0:
         t_b = ph[3] * 1e-6 if n_ph else None

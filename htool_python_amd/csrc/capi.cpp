@@ -3,6 +3,9 @@
 #include <cstring>
 #include <memory>
 #include <sstream>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../../include/htool_mi355x.h"
 #include "hmatrix.hpp"
@@ -56,6 +59,13 @@ const char *htool_device_name(void) {
     return s.c_str();
 }
 
+void htool_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 void htool_set_log_sink(htool_log_sink sink) { set_log_sink(sink); }
 void htool_test_logger(void) {
     log_message(LOG_CRITICAL, "Critical message");
@@ -271,7 +281,19 @@ int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, 
     const HMatrix &H = h->H;
     const size_t es = H.is_complex ? 16 : 8;
     const size_t nin = (size_t)H.sc->n_points, nout = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
-    for (int c = 0; c < mu; c++) matvec_scaled(H, alpha, (const char *)X + c * nin * es, beta, (char *)Y + c * nout * es);
+    bool plain;
+    if (H.is_complex) plain = (!alpha || *(const cplx *)alpha == cplx(1)) && (!beta || *(const cplx *)beta == cplx(0));
+    else plain = (!alpha || *(const double *)alpha == 1.0) && (!beta || *(const double *)beta == 0.0);
+    if (plain) device_matmat_host(H, X, mu, Y); // all right-hand sides in one sweep of the panels
+    else for (int c = 0; c < mu; c++) matvec_scaled(H, alpha, (const char *)X + c * nin * es, beta, (char *)Y + c * nout * es);
+    API_END
+}
+int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream) {
+    API_BEGIN
+    HM_CHECK(numbering >= 0 && numbering <= 2, "numbering must be 0 (user), 1 (cluster) or 2 (user in, cluster out)");
+    HM_CHECK(numbering != 0 || h->H.t_root == 0, "user-numbered output needs an H-matrix built on the whole target cluster");
+    HM_CHECK(mu >= 1, "mu must be >= 1");
+    device_matmat_device(h->H, X_dev, (long long)ldx, Y_dev, (long long)ldy, mu, numbering, stream);
     API_END
 }
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream) {
@@ -436,34 +458,38 @@ void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols) {
     *cols = d->sc->n_points;
 }
 
-static void distributed_product(const htool_distributed *d, const void *x, void *y) {
+static void distributed_product(const htool_distributed *d, const void *X, int mu, void *Y) {
     const HMatrix &H = d->hmat->H;
     const size_t es = H.is_complex ? 16 : 8;
-    const int nt = d->tc->n_points;
+    const int nt = d->tc->n_points, ns = d->sc->n_points;
     if (H.t_root == 0) { // one rank owning everything: plain user-numbered product
-        device_matvec_host(H, x, y);
+        if (mu == 1) device_matvec_host(H, X, Y);
+        else device_matmat_host(H, X, mu, Y);
         return;
     }
-    std::vector<char> local((size_t)H.row_size * es), full((size_t)nt * es);
-    device_matvec_host(H, x, local.data()); // local rows, cluster order
+    (void)ns;
+    std::vector<char> local((size_t)H.row_size * es * mu), full((size_t)nt * es);
+    if (mu == 1) device_matvec_host(H, X, local.data()); // local rows, cluster order
+    else device_matmat_host(H, X, mu, local.data());
     std::vector<int64_t> cb(d->counts.size()), db(d->displs.size());
     for (size_t p = 0; p < cb.size(); p++) { cb[p] = d->counts[p] * (int64_t)es; db[p] = d->displs[p] * (int64_t)es; }
     HM_CHECK(d->comm.allgatherv != nullptr, "communicator has no allgatherv");
-    int rc = d->comm.allgatherv(d->comm.ctx, local.data(), (int64_t)local.size(), full.data(), cb.data(), db.data());
-    HM_CHECK(rc == 0, "allgatherv failed");
-    for (int i = 0; i < nt; i++) std::memcpy((char *)y + (size_t)d->tc->perm[i] * es, &full[(size_t)i * es], es);
+    for (int c = 0; c < mu; c++) {
+        int rc = d->comm.allgatherv(d->comm.ctx, local.data() + (size_t)c * H.row_size * es, (int64_t)H.row_size * es, full.data(), cb.data(), db.data());
+        HM_CHECK(rc == 0, "allgatherv failed");
+        char *y = (char *)Y + (size_t)c * nt * es;
+        for (int i = 0; i < nt; i++) std::memcpy(y + (size_t)d->tc->perm[i] * es, &full[(size_t)i * es], es);
+    }
 }
 
 int htool_distributed_matvec(const htool_distributed *d, const void *x, void *y) {
     API_BEGIN
-    distributed_product(d, x, y);
+    distributed_product(d, x, 1, y);
     API_END
 }
 int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, void *Y) {
     API_BEGIN
-    const size_t es = d->hmat->H.is_complex ? 16 : 8;
-    const size_t nin = (size_t)d->sc->n_points, nout = (size_t)d->tc->n_points;
-    for (int c = 0; c < mu; c++) distributed_product(d, (const char *)X + c * nin * es, (char *)Y + c * nout * es);
+    distributed_product(d, X, mu, Y);
     API_END
 }
 }

@@ -65,19 +65,27 @@ __device__ __forceinline__ void store_rows(typename Ops::T *out, const GTile &tl
     }
 }
 
+// The kernels are templated on NR, the number of right-hand sides multiplied in one sweep of the panels
+// (H @ X, src/htool/hmatrix/hmatrix.hpp:134): every panel element is loaded once and used NR times, so the
+// arithmetic intensity is 0.25 NR flop/byte and the sweep stays HBM-bound up to NR = 8.  Right-hand side r
+// uses W + r * w_stride and writes out + r * out_stride.
+
 // ------------------------------------------------------------------------------------------------
 // phase B: few rows (<= 64*RPL), many columns; the four waves split the columns, LDS combine.
 // ------------------------------------------------------------------------------------------------
-template <typename Ops, int CH>
+template <typename Ops, int CH, int NR>
 __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
-                                                      const typename Ops::T *__restrict__ W, typename Ops::T *__restrict__ out) {
+                                                      const typename Ops::T *__restrict__ W, typename Ops::T *__restrict__ out,
+                                                      long long w_stride, long long out_stride) {
     typedef typename Ops::T T;
     const GTile tl = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = lane * Ops::RPL;
     const bool active = row0 < tl.nrows;
-    double2 acc = make_double2(0.0, 0.0);
+    double2 acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = make_double2(0.0, 0.0);
     for (int s = 0; s < tl.nseg; s++) {
         const GSeg sg = segs[tl.seg_begin + s];
         const T *base = (const T *)sg.panel + row0;
@@ -85,39 +93,56 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
         const int ncols = sg.ncols;
         for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
             const int nc = min(CH, ncols - c0);
-            T coef = Ops::zero();
-            if (lane < nc) coef = W[sg.cidx[c0 + lane]];
+            T coef[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
+            if (lane < nc) {
+                const long long ci = sg.cidx[c0 + lane];
+#pragma unroll
+                for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
+            }
             const T *p = base + (long long)c0 * ld;
             if (nc == CH) {
                 double2 v[CH];
 #pragma unroll
                 for (int u = 0; u < CH; u++) v[u] = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
-                for (int u = 0; u < CH; u++) Ops::fma(acc, v[u], Ops::bcast(coef, u));
+                for (int u = 0; u < CH; u++) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
+                }
             } else {
                 for (int u = 0; u < nc; u++) {
                     double2 v = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
-                    Ops::fma(acc, v, Ops::bcast(coef, u));
+#pragma unroll
+                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v, Ops::bcast(coef[r], u));
                 }
             }
         }
     }
-    __shared__ double2 red[4][64];
-    red[wave][lane] = acc;
+    __shared__ double2 red[NR][4][64];
+#pragma unroll
+    for (int r = 0; r < NR; r++) red[r][wave][lane] = acc[r];
     __syncthreads();
     if (wave == 0) {
-        double2 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
-        double2 sum = make_double2(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y);
-        store_rows<Ops>(out, tl, row0, tl.nrows, sum);
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            double2 a = red[r][0][lane], b = red[r][1][lane], c = red[r][2][lane], d = red[r][3][lane];
+            double2 sum = make_double2(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y);
+            store_rows<Ops>(out + r * out_stride, tl, row0, tl.nrows, sum);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // phase A / A2: many rows (cut in chunks of 64*RPL), few columns; each wave owns whole row chunks.
 // ------------------------------------------------------------------------------------------------
-template <typename Ops, int CH>
+template <typename Ops, int CH, int NR>
 __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
-                                                      const typename Ops::T *W, typename Ops::T *out) { // W and out alias (disjoint regions)
+                                                      const typename Ops::T *W, typename Ops::T *out, // W and out alias (disjoint regions)
+                                                      long long w_stride, long long out_stride, long long panel_stride) {
+    // panel_stride: 0 when all right-hand sides share the panel (phase A: V data); the distance between the
+    // per-right-hand-side panels otherwise (phase A2: the partial sums live in the coefficient workspace)
     typedef typename Ops::T T;
     constexpr int TM = 64 * Ops::RPL;
     const GTile tl = tiles[blockIdx.x];
@@ -132,49 +157,78 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
         const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
         const bool active = row0 < rows_here;
         const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0;
-        double2 acc = make_double2(0.0, 0.0);
+        double2 acc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) acc[r] = make_double2(0.0, 0.0);
         for (int c0 = 0; c0 < ncols; c0 += 64) {
             const int nc = min(64, ncols - c0);
-            T coef = Ops::zero();
-            if (lane < nc) coef = W[sg.cidx[c0 + lane]];
+            T coef[NR];
+#pragma unroll
+            for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
+            if (lane < nc) {
+                const long long ci = sg.cidx[c0 + lane];
+#pragma unroll
+                for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
+            }
             for (int cc = 0; cc < nc; cc += CH) {
                 const T *p = base + (long long)(c0 + cc) * ld;
-                if (cc + CH <= nc) {
+                if (NR > 1 && panel_stride != 0) {
+                    for (int u = 0; cc + u < nc && u < CH; u++) {
+#pragma unroll
+                        for (int r = 0; r < NR; r++) {
+                            double2 v = active ? *(const double2 *)(p + u * ld + r * panel_stride) : make_double2(0.0, 0.0);
+                            Ops::fma(acc[r], v, Ops::bcast(coef[r], cc + u));
+                        }
+                    }
+                } else if (cc + CH <= nc) {
                     double2 v[CH];
 #pragma unroll
                     for (int u = 0; u < CH; u++) v[u] = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int u = 0; u < CH; u++) Ops::fma(acc, v[u], Ops::bcast(coef, cc + u));
+                    for (int u = 0; u < CH; u++) {
+#pragma unroll
+                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], cc + u));
+                    }
                 } else {
                     for (int u = 0; cc + u < nc; u++) {
                         double2 v = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
-                        Ops::fma(acc, v, Ops::bcast(coef, cc + u));
+#pragma unroll
+                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v, Ops::bcast(coef[r], cc + u));
                     }
                 }
             }
         }
-        store_rows<Ops>(out, tl, q * TM + row0, tl.nrows, acc);
+#pragma unroll
+        for (int r = 0; r < NR; r++) store_rows<Ops>(out + r * out_stride, tl, q * TM + row0, tl.nrows, acc[r]);
     }
 }
 
+// W[r][i] = X[r][perm[i]] for the nr right-hand sides of one sweep
 template <typename T>
-__global__ void gather_x_kernel(const T *__restrict__ x, const int *__restrict__ perm, T *__restrict__ W, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) W[i] = x[perm[i]];
-}
-
-// y[map(i)] = sum_s ypart[s][i], slices added in order (deterministic); map = perm (user numbering) or identity
-template <typename T>
-__global__ void reduce_y_kernel(const T *__restrict__ ypart, long long stride, int nslices, int n, const int *__restrict__ perm, T *__restrict__ y) {
+__global__ void gather_x_kernel(const T *__restrict__ x, long long x_stride, const int *__restrict__ perm, T *__restrict__ W, long long w_stride, int n, int nr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    T acc = ypart[i];
-    for (int s = 1; s < nslices; s++) {
-        T v = ypart[(long long)s * stride + i];
-        if constexpr (sizeof(T) == 8) acc = acc + v;
-        else { acc.x += v.x; acc.y += v.y; }
+    const long long src = perm ? perm[i] : i;
+    for (int r = 0; r < nr; r++) W[r * w_stride + i] = x[r * x_stride + src];
+}
+
+// y[r][map(i)] = sum_s ypart[r][s][i], slices added in order (deterministic); map = perm (user numbering) or identity
+template <typename T>
+__global__ void reduce_y_kernel(const T *__restrict__ ypart, long long stride, int nslices, int n, const int *__restrict__ perm, T *__restrict__ y,
+                                long long y_stride, int nr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long dst = perm ? perm[i] : i;
+    for (int r = 0; r < nr; r++) {
+        const T *yp = ypart + (long long)r * nslices * stride;
+        T acc = yp[i];
+        for (int s = 1; s < nslices; s++) {
+            T v = yp[(long long)s * stride + i];
+            if constexpr (sizeof(T) == 8) acc = acc + v;
+            else { acc.x += v.x; acc.y += v.y; }
+        }
+        y[r * y_stride + dst] = acc;
     }
-    y[perm ? perm[i] : i] = acc;
 }
 
 template <typename T>
@@ -455,13 +509,14 @@ struct DeviceBuilder {
         const int TM = H.tile_max, Ns = Ss.n_points;
         std::vector<BatchTables> &tabs = D->tabs;
         const long long r_start = (Ns + 1 + 1) / 2 * 2;
-        D->W_elems = r_start + H.r_elems + 2;
+        D->W_elems = (r_start + H.r_elems + 2 + 1) / 2 * 2; // even: every right-hand-side copy stays 16-byte aligned
         HIP_OK(hipMalloc(&D->W, D->W_elems * sizeof(T)));
         HIP_OK(hipMemset(D->W, 0, D->W_elems * sizeof(T)));
         T one;
         std::memset(&one, 0, sizeof(T));
         *(double *)&one = 1.0;
         HIP_OK(hipMemcpy((char *)D->W + (size_t)Ns * sizeof(T), &one, sizeof(T), hipMemcpyHostToDevice));
+        D->rhs_cap = 1;
         D->perm_s = upload(Ss.perm, &D->table_bytes);
         D->perm_t = upload(Tt.perm, &D->table_bytes);
         std::vector<int> io(Ns);
@@ -630,40 +685,97 @@ void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems) 
     H.n_batches = (int)db.D->batches.size();
 }
 
-template <typename Ops>
-static void launch_product(DeviceHMatrix *D, const void *x_dev, void *y_dev, int numbering, hipStream_t st) {
+template <typename Ops, int NR>
+static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride, void *y_dev, long long y_stride, int numbering, hipStream_t st) {
     typedef typename Ops::T T;
     T *W = (T *)D->W;
     const int Ns = D->n_source;
+    const long long ws = D->W_elems;
     hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
     HIP_OK(hipEventRecord(ev[0], st));
-    if (numbering == 0 || numbering == 2) {
-        if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, D->perm_s, W, Ns);
-    } else {
-        HIP_OK(hipMemcpyAsync(W, x_dev, (size_t)Ns * sizeof(T), hipMemcpyDeviceToDevice, st));
-    }
+    if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, x_stride, (numbering == 0 || numbering == 2) ? D->perm_s : (const int *)nullptr, W, ws, Ns, NR);
     HIP_OK(hipEventRecord(ev[1], st));
-    if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W);
+    if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W, ws, ws, 0LL);
     HIP_OK(hipEventRecord(ev[2], st));
-    if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W);
+    if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W, ws, ws, ws);
     HIP_OK(hipEventRecord(ev[3], st));
     if (D->splitB > 1 && D->nB_split) {
-        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, (T *)D->ypart);
+        const long long ps = (long long)D->splitB * D->ypart_stride;
+        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, (T *)D->ypart, ws, ps);
         hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
-                           numbering == 0 ? D->perm_t + D->row_off : nullptr, (T *)y_dev);
-    } else if (D->nB) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev);
+                           numbering == 0 ? D->perm_t + D->row_off : (const int *)nullptr, (T *)y_dev, y_stride, NR);
+    } else if (D->nB) {
+        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev, ws, y_stride);
+    }
     HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
     D->nprod++;
 }
 
-void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream) {
+// make room for nr coefficient workspaces (and partial-y slabs); W[r][n_source] = 1 for every r
+template <typename T>
+static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
+    if (nr <= D->rhs_cap) return;
+    void *nW = nullptr;
+    HIP_OK(hipMalloc(&nW, (size_t)nr * D->W_elems * sizeof(T)));
+    HIP_OK(hipMemset(nW, 0, (size_t)nr * D->W_elems * sizeof(T)));
+    T one;
+    std::memset(&one, 0, sizeof(T));
+    *(double *)&one = 1.0;
+    for (int r = 0; r < nr; r++) HIP_OK(hipMemcpy((char *)nW + ((size_t)r * D->W_elems + D->n_source) * sizeof(T), &one, sizeof(T), hipMemcpyHostToDevice));
+    // A2 segments point into W: relocate them
+    if (D->W && D->nA2) {
+        std::vector<GTile> t((size_t)D->nA2);
+        HIP_OK(hipMemcpy(t.data(), D->tilesA2, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
+        for (auto &x : t) {
+            GSeg sg;
+            HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
+            sg.panel = (const char *)nW + ((const char *)sg.panel - (const char *)D->W);
+            HIP_OK(hipMemcpy(D->segs + x.seg_begin, &sg, sizeof(GSeg), hipMemcpyHostToDevice));
+        }
+    }
+    if (D->W) (void)hipFree(D->W);
+    D->W = nW;
+    if (D->splitB > 1) {
+        if (D->ypart) (void)hipFree(D->ypart);
+        HIP_OK(hipMalloc(&D->ypart, (size_t)nr * D->splitB * D->ypart_stride * sizeof(T)));
+    }
+    D->rhs_cap = nr;
+}
+
+template <typename Ops>
+static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, hipStream_t st) {
+    typedef typename Ops::T T;
+    int done = 0;
+    while (done < mu) {
+        const int left = mu - done;
+        const T *x = (const T *)X + (long long)done * x_stride;
+        T *y = (T *)Y + (long long)done * y_stride;
+        if (left >= 8) { launch_sweep<Ops, 8>(D, x, x_stride, y, y_stride, numbering, st); done += 8; }
+        else if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
+        else if (left >= 2) { launch_sweep<Ops, 2>(D, x, x_stride, y, y_stride, numbering, st); done += 2; }
+        else { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; }
+    }
+}
+
+// Y = H X for mu right-hand sides stored with the given strides (elements); mu = 1 is the matvec
+void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
-    if (D->is_complex) launch_product<CplxOps>(D, x_dev, y_dev, numbering, st);
-    else launch_product<RealOps>(D, x_dev, y_dev, numbering, st);
+    const int need = mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1;
+    if (need > D->rhs_cap) {
+        HIP_OK(hipStreamSynchronize(st));
+        if (D->is_complex) ensure_rhs_capacity<double2>(D, need);
+        else ensure_rhs_capacity<double>(D, need);
+    }
+    if (D->is_complex) launch_product<CplxOps>(D, X, x_stride, Y, y_stride, mu, numbering, st);
+    else launch_product<RealOps>(D, X, x_stride, Y, y_stride, mu, numbering, st);
+}
+
+void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream) {
+    device_matmat_device(H, x_dev, 0, y_dev, 0, 1, numbering, stream);
 }
 
 void device_matvec_host(const HMatrix &H, const void *x, void *y) {
@@ -678,6 +790,25 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     device_matvec_device(H, D->x_tmp, D->y_tmp, whole ? 0 : 2, D->stream);
     HIP_OK(hipMemcpyAsync(y, D->y_tmp, (size_t)(whole ? D->n_target : D->row_size) * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
+}
+
+// Y = H X on host buffers, X column-major n_source x mu (user numbering), all right-hand sides in one go
+void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
+    DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HIP_OK(hipSetDevice(D->device));
+    const size_t es = D->esize;
+    const bool whole = H.t_root == 0;
+    const size_t nin = (size_t)D->n_source, nout = (size_t)(whole ? D->n_target : D->row_size);
+    void *dX = nullptr, *dY = nullptr;
+    HIP_OK(hipMalloc(&dX, std::max<size_t>(nin * mu, 1) * es));
+    HIP_OK(hipMalloc(&dY, std::max<size_t>(nout * mu, 1) * es));
+    HIP_OK(hipMemcpyAsync(dX, X, nin * mu * es, hipMemcpyHostToDevice, D->stream));
+    device_matmat_device(H, dX, (long long)nin, dY, (long long)nout, mu, whole ? 0 : 2, D->stream);
+    HIP_OK(hipMemcpyAsync(Y, dY, nout * mu * es, hipMemcpyDeviceToHost, D->stream));
+    HIP_OK(hipStreamSynchronize(D->stream));
+    (void)hipFree(dX);
+    (void)hipFree(dY);
 }
 
 // average duration (microseconds) of the four launches over the completed products still in the ring:

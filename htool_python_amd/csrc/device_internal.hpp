@@ -64,7 +64,8 @@ struct DeviceHMatrix {
     long long ypart_stride = 0;
     int *perm_s = nullptr, *perm_t = nullptr, *iota = nullptr, *ones_idx = nullptr;
     void *W = nullptr;
-    long long W_elems = 0;
+    long long W_elems = 0;   // elements of ONE coefficient workspace; W holds rhs_cap of them back to back
+    int rhs_cap = 0;
     void *x_tmp = nullptr, *y_tmp = nullptr;
     int n_source = 0, n_target = 0, row_off = 0, row_size = 0;
     hipStream_t stream = nullptr;

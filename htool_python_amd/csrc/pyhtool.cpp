@@ -467,6 +467,9 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("matvec_device", [](const H &s, std::uintptr_t x_dev, std::uintptr_t y_dev, int numbering, std::uintptr_t stream) {
                 check(htool_hmatrix_matvec_device(s.h, (const void *)x_dev, (void *)y_dev, numbering, (void *)stream));
             }, "x_ptr"_a, "y_ptr"_a, "numbering"_a = 0, "stream"_a = 0)
+        .def("matmat_device", [](const H &s, std::uintptr_t x_dev, long long ldx, std::uintptr_t y_dev, long long ldy, int mu, int numbering, std::uintptr_t stream) {
+                check(htool_hmatrix_matmat_device(s.h, (const void *)x_dev, ldx, (void *)y_dev, ldy, mu, numbering, (void *)stream));
+            }, "x_ptr"_a, "ldx"_a, "y_ptr"_a, "ldy"_a, "mu"_a, "numbering"_a = 0, "stream"_a = 0)
         .def_property_readonly("_handle", [](const H &s) { return (std::uintptr_t)s.h; });
 
     m.def("recompression", [](H &) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
@@ -516,6 +519,7 @@ PYBIND11_MODULE(Htool, m) {
     m.def("device_count", &htool_device_count);
     m.def("device_name", []() { return std::string(htool_device_name()); });
     m.def("set_device", [](int d) { check(htool_set_device(d)); });
+    m.def("set_num_threads", &htool_set_num_threads);
 
     py::class_<PyCluster>(m, "Cluster")
         .def("get_size", [](const PyCluster &c) { return htool_cluster_size(c.node); })

@@ -24,3 +24,17 @@ def algorithmic_bytes(leaves, n_source, n_rows, elem_bytes):
     phase_a = elem_bytes * (rv + n_source)
     phase_b = elem_bytes * (d + ru + n_rows)
     return {"total": phase_a + phase_b, "phase_a": phase_a, "phase_b": phase_b, "dense_elements": d, "u_elements": ru, "v_elements": rv}
+
+
+def usable_cpus():
+    """CPUs this process may really use: min(affinity mask, cgroup CPU quota)."""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)

@@ -38,6 +38,7 @@ const char *htool_last_error(void);
 int htool_device_count(void);          /* number of usable HIP devices (0 on a GPU-less box) */
 int htool_set_device(int device);      /* select the HIP device for objects created afterwards */
 const char *htool_device_name(void);   /* e.g. "gfx950:..." or "" */
+void htool_set_num_threads(int n);     /* OpenMP threads of the host-side tree construction (0: leave as is) */
 
 /* replaces PythonLoggerWriter / htool::Logger (misc/logger.hpp:10-37, main.cpp:42).
  * levels: 0 CRITICAL, 1 ERROR, 2 WARNING, 3 DEBUG, 4 INFO (order of logger.hpp:17-32) */
@@ -135,6 +136,9 @@ int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, 
  * 1 = cluster in and out (x is the whole permuted source vector, y the local row slice),
  * 2 = user in, cluster (local row slice) out.  stream = hipStream_t. */
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream);
+/* Y = H X on device buffers: mu right-hand sides, column c of X at X_dev + c*ldx elements (same for Y).
+ * All columns are multiplied in sweeps of up to 8 right-hand sides per pass over the panels. */
+int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream);
 
 /* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
 int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);

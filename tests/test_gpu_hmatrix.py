@@ -166,3 +166,32 @@ def test_custom_dense_blocks_generator(built, oracle):
     x = np.random.rand(400)
     ye = gen.mat_vec(x)
     assert np.linalg.norm(H * x - ye) / np.linalg.norm(ye) < 1e-6
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
+    """H @ X multiplies up to 8 right-hand sides per sweep of the panels (src/htool/hmatrix/hmatrix.hpp:119-138);
+    every column must equal the single-vector product bit for bit (same summation order), for any mu."""
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    n = 5000
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 40)
+    if complex_:
+        H = Htool.ComplexHMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.ComplexNativeGenerator("helmholtz", pts, pts, 6.0), cl, cl)
+    else:
+        H = Htool.HMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts), cl, cl)
+    for mu in (1, 2, 3, 5, 8, 11, 16):
+        X = np.random.rand(n, mu) + (1j * np.random.rand(n, mu) if complex_ else 0)
+        X = np.asfortranarray(X)
+        Y = H @ X
+        assert Y.shape == (n, mu) and Y.flags.f_contiguous
+        for c in range(mu):
+            assert np.array_equal(Y[:, c], H * np.ascontiguousarray(X[:, c]))
+    Ye = O.dense_matvec(O.K_HELMHOLTZ if complex_ else O.K_LAPLACE, pts, pts, X, 6.0 if complex_ else 0.0)
+    assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-4
+    with pytest.raises(RuntimeError, match="Wrong size for HMatrix-matrix product"):
+        H @ np.zeros((n + 1, 2), order="F")
