@@ -102,6 +102,9 @@ def main():
                     help="nccl (= RCCL, one GPU per rank) is the measured path; gloo stages the exchange through the host so that the "
                          "multi-rank logic can be rehearsed with several ranks on ONE GPU (not a benchmark)")
     ap.add_argument("--rhs", type=int, default=1, help="right-hand sides per step (H @ X, one sweep of the panels per 8 columns); 1 = the headline matvec")
+    ap.add_argument("--gmres", type=int, default=0, help="BASELINE config 5: instead of bare products, a step is ONE GMRES iteration (restart = this value) "
+                                                        "on (shift I + H) with device-resident Krylov vectors")
+    ap.add_argument("--shift", type=float, default=0.0, help="diagonal shift of the --gmres system (0: N/50, keeps the system well posed)")
     ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
     args = ap.parse_args()
 
@@ -203,15 +206,35 @@ def main():
                 dist.all_gather(parts, x_local)
             H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
 
-    for _ in range(args.warmup):
+    gmres_info = None
+    if args.gmres > 0:
+        from htool_python_amd.krylov import gmres
+        from htool_python_amd.solver import DeviceOperator
+
+        part = [(cluster.get_cluster_on_partition(p).get_offset(), cluster.get_cluster_on_partition(p).get_size()) for p in range(world)] if world > 1 else None
+        shift = args.shift if args.shift != 0.0 else n / 50.0
+        op = DeviceOperator(H, part, rank, None, shift)
+        b_local = torch.rand(op.size, dtype=torch.float64, generator=gen_t).to(dtype).cuda()
+        red = op.reduce if world > 1 else None
+        args.steps = args.gmres
+
+        def run_gmres():
+            return gmres(op.apply, b_local, tol=0.0, restart=args.gmres, max_it=args.gmres, reduce=red)
+
+        run_gmres()  # warm-up cycle (allocations, RCCL channels)
+        step = None
+    for _ in range(args.warmup if step is not None else 0):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if step is None:
+        _, gmres_info = run_gmres()
+    else:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -269,6 +292,9 @@ def main():
         "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,
         "rhs_per_step": args.rhs,
+        "gmres": None if gmres_info is None else {"iterations": gmres_info["iterations"], "s_per_iteration": dt / max(gmres_info["iterations"], 1),
+                                                   "relative_residuals": [gmres_info["residuals"][i] for i in (0, len(gmres_info["residuals"]) // 2, -1)],
+                                                   "note": "step = one GMRES iteration (1 product + CGS2 orthogonalisation) on (shift I + H), no preconditioner"},
     }
     if rank == 0:
         t_b = ph[3] * 1e-6 if n_ph else None

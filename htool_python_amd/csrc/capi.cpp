@@ -458,6 +458,7 @@ void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols) {
     *cols = d->sc->n_points;
 }
 
+} // extern "C"
 static void distributed_product(const htool_distributed *d, const void *X, int mu, void *Y) {
     const HMatrix &H = d->hmat->H;
     const size_t es = H.is_complex ? 16 : 8;
@@ -482,6 +483,14 @@ static void distributed_product(const htool_distributed *d, const void *X, int m
     }
 }
 
+extern "C" {
+int htool_distributed_partition(const htool_distributed *d, int p, int *offset, int *size) {
+    API_BEGIN
+    HM_CHECK(p >= 0 && p < (int)d->counts.size(), "partition index out of range");
+    *offset = (int)d->displs[p];
+    *size = (int)d->counts[p];
+    API_END
+}
 int htool_distributed_matvec(const htool_distributed *d, const void *x, void *y) {
     API_BEGIN
     distributed_product(d, x, 1, y);

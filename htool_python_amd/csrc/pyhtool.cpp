@@ -327,6 +327,7 @@ template <typename T>
 struct PyDistributedOperator {
     htool_distributed *d = nullptr;
     std::shared_ptr<PyComm> comm;
+    PyHMatrix<T> *local = nullptr; // owned by the approximation builder that created this operator
     py::array_t<T, py::array::f_style> mul(const py::array_t<T, py::array::f_style> &input) const {
         int rows, cols;
         htool_distributed_shape(d, &rows, &cols);
@@ -363,6 +364,7 @@ struct PyDefaultApproximationBuilder {
         check(htool_distributed_create_default(generator.get(), t.owner->root, s.owner->root, &q, &comm->c, &d));
         op.d = d;
         op.comm = comm;
+        op.local = &hmat;
         hmat.h = htool_distributed_hmatrix(d);
         hmat.owned = false;
         hmat.target = t;
@@ -503,7 +505,19 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 return std::pair<int, int>(r, c);
             })
         .def("__mul__", &Op::mul, "in"_a)
-        .def("__matmul__", &Op::matmul, py::arg("input").noconvert(true));
+        .def("__matmul__", &Op::matmul, py::arg("input").noconvert(true))
+        // extensions used by the GPU-resident Krylov loop (htool_python_amd/solver.py)
+        .def_property_readonly("local_hmatrix", [](Op &o) { return o.local; }, py::return_value_policy::reference_internal)
+        .def_property_readonly("comm", [](Op &o) { return o.comm->obj; })
+        .def("partition", [](Op &o) {
+                std::vector<std::pair<int, int>> out;
+                for (int p = 0; p < o.comm->c.size; p++) {
+                    int off = 0, sz = 0;
+                    check(htool_distributed_partition(o.d, p, &off, &sz));
+                    out.emplace_back(off, sz);
+                }
+                return out;
+            });
     typedef PyDefaultApproximationBuilder<T> DA;
     py::class_<DA>(m, (prefix + "DefaultApproximationBuilder").c_str())
         .def(py::init<PyIGenerator<T> &, const PyCluster &, const PyCluster &, const B &, py::object>())

@@ -1,0 +1,169 @@
+"""Krylov solver behind the reference's solver surface.
+
+Reference: `Htool.DDMSolverBuilder(distributed_operator, block_diagonal_hmatrix).solver`, then
+`solver.facto_one_level()`, `solver.set_hpddm_args(str)`, `solver.solve(x, b, hpddm_args)`,
+`solver.get_information()` (src/htool/solver/utility.hpp:7-61, src/htool/solver/solver.hpp:16-66,
+example/use_ddm_solver.py:49-69).  The reference delegates to HPDDM (absent); here the Krylov loop is the
+package's own restarted GMRES on GPU-resident vectors (krylov.py) with the H-matrix product as operator.
+Only the options the reference's tests use are parsed (tests/test_ddm_solver.py:550-558):
+-hpddm_krylov_method gmres, -hpddm_tol, -hpddm_max_it, -hpddm_gmres_restart, -hpddm_variant right.
+No preconditioner is applied (block-Jacobi/Schwarz/GenEO are out of scope):
+`facto_one_level()` is a no-op and the `block_diagonal_hmatrix` argument is ignored.
+"""
+import time
+
+import numpy as np
+import torch
+
+
+def _parse_hpddm(args, opts):
+    tok = args.split()
+    i = 0
+    while i < len(tok):
+        key = tok[i]
+        val = tok[i + 1] if i + 1 < len(tok) and not tok[i + 1].startswith("-hpddm") else None
+        if key == "-hpddm_tol" and val:
+            opts["tol"] = float(val)
+        elif key == "-hpddm_max_it" and val:
+            opts["max_it"] = int(val)
+        elif key == "-hpddm_gmres_restart" and val:
+            opts["restart"] = int(val)
+        elif key == "-hpddm_krylov_method" and val:
+            if val != "gmres":
+                raise ValueError(f"only -hpddm_krylov_method gmres is implemented (got {val})")
+        i += 2 if val is not None else 1
+    return opts
+
+
+class DeviceOperator:
+    """y_local = (shift I + A) x on GPU-resident slices in cluster numbering; A = this rank's rows."""
+
+    def __init__(self, hmatrix, partition=None, rank=0, group=None, shift=0.0):
+        self.H = hmatrix
+        self.n = hmatrix.shape[1]
+        self.partition = partition or [(0, self.n)]
+        self.rank, self.world = rank, len(self.partition)
+        self.group, self.shift = group, shift
+        self.offset, self.size = self.partition[rank]
+        self.products = 0
+        self._full = None
+
+    def apply(self, x_local):
+        import torch.distributed as dist
+
+        y = torch.empty(self.size, dtype=x_local.dtype, device=x_local.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        if self.world == 1:
+            xf = x_local.contiguous()
+        else:
+            if self._full is None:
+                self._full = torch.empty(self.n, dtype=x_local.dtype, device=x_local.device)
+            sizes = [s for _, s in self.partition]
+            if dist.get_backend(self.group) == "nccl":
+                if len(set(sizes)) == 1:
+                    dist.all_gather_into_tensor(self._full, x_local.contiguous(), group=self.group)
+                else:
+                    dist.all_gather(list(torch.split(self._full, sizes)), x_local.contiguous(), group=self.group)
+            else:  # host-staged exchange (gloo): several ranks may share one GPU
+                parts = [torch.empty(s, dtype=x_local.dtype) for s in sizes]
+                dist.all_gather(parts, x_local.cpu(), group=self.group)
+                self._full.copy_(torch.cat(parts))
+            xf = self._full
+        self.H.matvec_device(xf.data_ptr(), y.data_ptr(), 1, stream)
+        self.products += 1
+        if self.shift != 0.0:
+            y += self.shift * x_local
+        return y
+
+    def reduce(self, t):
+        import torch.distributed as dist
+
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(t, group=self.group)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+        return t
+
+
+class Solver:
+    def __init__(self, distributed_operator=None, hmatrix=None, shift=0.0):
+        from .krylov import gmres
+
+        self._gmres = gmres
+        self._opts = {"tol": 1e-6, "max_it": 200, "restart": 50}
+        self._info = {}
+        if distributed_operator is not None:
+            H = distributed_operator.local_hmatrix
+            comm = distributed_operator.comm
+            part = distributed_operator.partition()
+            rank = comm.Get_rank()
+            group = None
+            if len(part) > 1:
+                comm._dist()  # make sure the process group exists
+            self.op = DeviceOperator(H, part, rank, group, shift)
+        else:
+            self.op = DeviceOperator(hmatrix, None, 0, None, shift)
+        assert self.op.H.shape[1] == sum(s for _, s in self.op.partition), "GMRES needs a square operator"
+        self._perm = np.asarray(self.op.H.get_source_cluster().get_permutation())
+
+    def facto_one_level(self):
+        """No preconditioner (see module docstring)."""
+
+    def build_coarse_space(self, *a, **k):
+        raise RuntimeError("GenEO coarse spaces are outside the MI355X hot path; not implemented")
+
+    def set_hpddm_args(self, hpddm_args):
+        _parse_hpddm(hpddm_args, self._opts)
+
+    def solve(self, x, b, hpddm_args=""):
+        """x (in/out, numpy, user numbering) <- solution of A x = b; several right-hand sides column by column."""
+        _parse_hpddm(hpddm_args, self._opts)
+        if b.ndim != x.ndim or (b.ndim == 2 and b.shape[1] != x.shape[1]) or b.ndim > 2:
+            raise ValueError(f"Wrong dimension for right-hand side or solution\nright-hand side: {b.shape}\nsolution: {x.shape}\n")
+        cols = [(x, b)] if b.ndim == 1 else [(x[:, c], b[:, c]) for c in range(b.shape[1])]
+        off, size = self.op.offset, self.op.size
+        t0 = time.time()
+        its, res = [], []
+        for xc, bc in cols:
+            bl = torch.from_numpy(np.ascontiguousarray(np.asarray(bc)[self._perm][off:off + size])).cuda()
+            x0 = None
+            if np.any(np.asarray(xc) != 0):
+                x0 = torch.from_numpy(np.ascontiguousarray(np.asarray(xc)[self._perm][off:off + size])).cuda()
+            xl, info = self._gmres(self.op.apply, bl, x0, self._opts["tol"], self._opts["restart"], self._opts["max_it"], self.op.reduce if self.op.world > 1 else None)
+            full = self._gather(xl)
+            out = np.empty_like(full)
+            out[self._perm] = full
+            xc[...] = out
+            its.append(info["iterations"])
+            res.append(info["residuals"][-1] if info["residuals"] else 0.0)
+            self._history = info["residuals"]
+        self._info = {"Nb_it": str(max(its)), "Relative_residual": str(max(res)), "Solve_seconds": str(time.time() - t0),
+                      "Products": str(self.op.products), "Krylov_method": "gmres", "Preconditioner": "none"}
+
+    def _gather(self, xl):
+        import torch.distributed as dist
+
+        if self.op.world == 1:
+            return xl.cpu().numpy()
+        parts = [torch.empty(s, dtype=xl.dtype) for _, s in self.op.partition]
+        host = xl.cpu()
+        if dist.get_backend(self.op.group) == "nccl":
+            dev = [p.cuda() for p in parts]
+            dist.all_gather(dev, xl.contiguous(), group=self.op.group)
+            parts = [p.cpu() for p in dev]
+        else:
+            dist.all_gather(parts, host, group=self.op.group)
+        return torch.cat(parts).numpy()
+
+    def get_information(self):
+        return dict(self._info)
+
+
+class DDMSolverBuilder:
+    """Htool.DDMSolverBuilder(distributed_operator, block_diagonal_hmatrix).solver (src/htool/solver/utility.hpp:7-61)."""
+
+    def __init__(self, distributed_operator, block_diagonal_hmatrix=None, *args, **kwargs):
+        self.solver = Solver(distributed_operator)

@@ -191,6 +191,8 @@ void htool_distributed_destroy(htool_distributed *d);
 htool_hmatrix *htool_distributed_hmatrix(htool_distributed *d);                /* utility.hpp:29, borrowed */
 htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *d); /* utility.hpp:31, borrowed */
 void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols); /* distributed_operator.hpp:18 */
+/* rows owned by rank p, as a range of cluster numbering (the depth-1 partition of the target tree) */
+int htool_distributed_partition(const htool_distributed *d, int p, int *offset, int *size);
 /* replicated user-numbered x in, replicated y out (distributed_operator.hpp:23-65) */
 int htool_distributed_matvec(const htool_distributed *d, const void *x, void *y);
 int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, void *Y);

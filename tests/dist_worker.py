@@ -74,6 +74,26 @@ def main(mode):
                 # every rank returns the same replicated result
                 ysum = comm.allreduce(y, op=mpi4py.MPI.SUM)
                 assert np.allclose(ysum, world * y, rtol=1e-13, atol=0)
+        # Krylov solve through the reference's solver surface (example/use_ddm_solver.py:49-69; our own GMRES,
+        # no preconditioner): square symmetric operator on the target cloud, rows split over the ranks
+        gen = Htool.NativeGenerator("inv_delta", T, T, 0.1)
+        holder = Htool.DefaultApproximationBuilder(gen, tcl, tcl, Htool.HMatrixTreeBuilder(1e-8, 10.0, "S", "L"), comm)
+        solver = Htool.DDMSolverBuilder(holder.distributed_operator, holder.block_diagonal_hmatrix).solver
+        np.random.seed(3)
+        x_ref = np.random.random(400)
+        bb = holder.distributed_operator * x_ref
+        x = np.zeros(400)
+        solver.set_hpddm_args("-hpddm_compute_residual l2 ")
+        solver.facto_one_level()
+        solver.solve(x, bb, "-hpddm_krylov_method gmres -hpddm_variant right -hpddm_tol 1e-9 -hpddm_max_it 400 -hpddm_gmres_restart 200")
+        A = O.kernel_block(O.K_INV_DELTA, T, T, 0.1)
+        info = solver.get_information()
+        assert float(info["Relative_residual"]) <= 1e-9, info
+        assert np.linalg.norm(A @ x - bb) / np.linalg.norm(bb) < 1e-6
+        assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-3
+        X2, B2 = np.zeros((400, 2), order="F"), np.asfortranarray(np.stack([bb, 2 * bb], axis=1))
+        solver.solve(X2, B2)
+        assert np.linalg.norm(X2[:, 1] - 2 * X2[:, 0]) / np.linalg.norm(X2[:, 1]) < 1e-6
         # partitioned geometry of example/use_distributed_operator.py (local partition given), world == 2 only
         if world == 2:
             gp = np.load(os.path.join(ROOT, "tests", "golden", "partitioned_1000_w2.npz"))

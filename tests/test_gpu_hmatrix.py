@@ -195,3 +195,42 @@ def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
     assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-4
     with pytest.raises(RuntimeError, match="Wrong size for HMatrix-matrix product"):
         H @ np.zeros((n + 1, 2), order="F")
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_gmres_on_device(built, oracle, complex_):
+    """GMRES with the HIP product as operator: converges to the solution of the dense system
+    (tests/test_ddm_solver.py:659-660 bar: residual < tol, |x - x_ref| / |x_ref| < 10 eps)."""
+    import torch
+
+    import Htool
+    from htool_python_amd.krylov import gmres
+    from htool_python_amd.solver import DeviceOperator
+    from tests.helpers import cluster_of
+
+    O = oracle
+    n, eps = 3000, 1e-8
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 32)
+    if complex_:
+        kind, p0 = O.K_HELMHOLTZ, 3.0
+        H = Htool.ComplexHMatrixTreeBuilder(eps, 10.0, "N", "N").build(Htool.ComplexNativeGenerator("helmholtz", pts, pts, p0), cl, cl)
+    else:
+        kind, p0 = O.K_INV_DELTA, 0.1
+        H = Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N").build(Htool.NativeGenerator("inv_delta", pts, pts, p0), cl, cl)
+    shift = 50.0  # second-kind-like, well conditioned: (shift I + A) x = b
+    A = O.kernel_block(kind, pts, pts, p0) + shift * np.eye(n)
+    x_ref = np.random.rand(n) + (1j * np.random.rand(n) if complex_ else 0)
+    b = A @ x_ref
+    perm = np.asarray(cl.get_permutation())
+    op = DeviceOperator(H, shift=shift)
+    xl, info = gmres(op.apply, torch.from_numpy(b[perm]).cuda(), tol=1e-10, restart=30, max_it=300)
+    x = np.empty_like(b)
+    x[perm] = xl.cpu().numpy()
+    assert info["converged"] and info["residuals"][-1] <= 1e-10
+    assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-7
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    # residual history is non-increasing within a restart cycle
+    r = np.array(info["residuals"][:30])
+    assert np.all(r[1:] <= r[:-1] * (1 + 1e-12))
