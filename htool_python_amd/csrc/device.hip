@@ -29,6 +29,14 @@ __device__ __forceinline__ double bcast_f64(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+typedef double dvec2_t __attribute__((ext_vector_type(2)));
+// 16-byte streaming load of panel data (read exactly once per product): non-temporal hint keeps the
+// coefficient workspace W resident in L2 / Infinity Cache instead
+__device__ __forceinline__ double2 ldnt16(const void *p) {
+    dvec2_t v = __builtin_nontemporal_load((const dvec2_t *)p);
+    return make_double2(v.x, v.y);
+}
+
 struct RealOps {
     typedef double T;
     static constexpr int RPL = 2; // rows per lane
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
             if (nc == CH) {
                 double2 v[CH];
 #pragma unroll
-                for (int u = 0; u < CH; u++) v[u] = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+                for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
                 for (int u = 0; u < CH; u++) {
 #pragma unroll
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
                 }
             } else {
                 for (int u = 0; u < nc; u++) {
-                    double2 v = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+                    double2 v = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
                     for (int r = 0; r < NR; r++) Ops::fma(acc[r], v, Ops::bcast(coef[r], u));
                 }
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
                 } else if (cc + CH <= nc) {
                     double2 v[CH];
 #pragma unroll
-                    for (int u = 0; u < CH; u++) v[u] = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+                    for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
                     for (int u = 0; u < CH; u++) {
 #pragma unroll
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
                     }
                 } else {
                     for (int u = 0; cc + u < nc; u++) {
-                        double2 v = active ? *(const double2 *)(p + u * ld) : make_double2(0.0, 0.0);
+                        double2 v = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
                         for (int r = 0; r < NR; r++) Ops::fma(acc[r], v, Ops::bcast(coef[r], cc + u));
                     }

@@ -234,3 +234,46 @@ def test_gmres_on_device(built, oracle, complex_):
     # residual history is non-increasing within a restart cycle
     r = np.array(info["residuals"][:30])
     assert np.all(r[1:] <= r[:-1] * (1 + 1e-12))
+
+
+@pytest.mark.parametrize("n_t,n_s,dim,children,leaf,eta", [
+    (1, 1, 3, 2, 10, 10.0),        # a single entry
+    (7, 5, 2, 2, 10, 10.0),        # smaller than a leaf: one dense block
+    (37, 211, 3, 2, 3, 1.0),       # odd sizes, tiny leaves (tiles of 3..5 rows)
+    (513, 129, 1, 2, 1, 10.0),     # 1-D points, leaves of a single point
+    (600, 600, 2, 3, 7, 10.0),     # ternary tree
+    (1000, 333, 3, 9, 5, 0.5),     # 9 children, strict admissibility
+    (300, 2500, 3, 2, 200, 10.0),  # leaves larger than a tile (cut in pieces)
+])
+def test_edge_shapes(built, oracle, n_t, n_s, dim, children, leaf, eta):
+    """Ragged / degenerate inputs: the product must still equal the exact dense operator to epsilon and the
+    CPU leaf loop on the same panels to rounding, for both build paths."""
+    import Htool
+    from tests.helpers import NumpyGenerator, cpu_leaf_loop
+
+    O = oracle
+    rng = np.random.RandomState(n_t + 7 * n_s)
+    T, S = rng.rand(dim, n_t), rng.rand(dim, n_s) + 0.25
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    tcl, scl = b.create_cluster_tree(T, children), b.create_cluster_tree(S, children)
+    eps = 1e-6
+    x = rng.rand(n_s)
+    ye = O.dense_matvec(O.K_INV_DELTA, T, S, x, 0.1)
+    for native in (True, False):
+        gen = Htool.NativeGenerator("inv_delta", T, S, 0.1) if native else NumpyGenerator(T, S)
+        H = Htool.HMatrixTreeBuilder(eps, eta, "N", "N").build(gen, tcl, scl)
+        assert H.shape == (n_t, n_s)
+        y = H * x
+        assert y.shape == (n_t,)
+        assert np.linalg.norm(y - ye) <= eps * np.linalg.norm(ye) + 1e-300
+        yc = cpu_leaf_loop(H, x)
+        assert np.linalg.norm(y - yc) <= 1e-12 * np.linalg.norm(yc) + 1e-300
+        L = np.asarray(H.leaves()).astype(np.int64)
+        assert (L[:, 1] * L[:, 3]).sum() == n_t * n_s
+        X = np.asfortranarray(rng.rand(n_s, 3))
+        Y = H @ X
+        for c in range(3):
+            assert np.array_equal(Y[:, c], H * np.ascontiguousarray(X[:, c]))
+        D = H.to_dense_in_user_numbering()
+        assert np.linalg.norm(D @ x - y) <= 1e-10 * np.linalg.norm(y) + 1e-300
