@@ -99,9 +99,7 @@ TileSet make_tiles(const ClusterTree &T, int root_node, int tile_max) {
     ts.node_tile_begin.assign(nn, 0);
     ts.node_tile_end.assign(nn, 0);
     // depth-first walk in offset order; leaves are cut into ceil(size/tile_max) nearly equal pieces
-    std::vector<int> stack{root_node};
-    std::vector<int> order; // post-order bookkeeping
-    std::vector<std::pair<int, int>> st;
+    std::vector<std::pair<int, int>> st; // (node, phase): phase 0 = entering, 1 = leaving
     st.push_back(std::make_pair(root_node, 0));
     while (!st.empty()) {
         int id = st.back().first, phase = st.back().second;
