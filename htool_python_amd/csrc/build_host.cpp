@@ -26,19 +26,26 @@ inline cplx cj(const cplx &x) { return std::conj(x); }
 inline double re(double x) { return x; }
 inline double re(const cplx &x) { return x.real(); }
 
-// returns rank (>=0) or -1 when the block is not worth storing in low-rank form
+// returns rank (>=0) or -1 when the block is not worth storing in low-rank form.
+// swp: run on the transposed block ("sym" role rule, SURVEY.md A.4: leaves below the diagonal), so that for a
+// symmetric generator the leaves (t,s) and (s,t) get exactly transposed factors.  U (M0 x r, [k][i]) and
+// V (r x N0, [k][j]) always refer to the block as given.
 template <typename T>
-int host_aca(const Generator &g, int M, int N, const int *rows, const int *cols, double eps, int reqrank, std::vector<T> &U, std::vector<T> &V) {
-    U.clear();
-    V.clear();
+int host_aca(const Generator &g, int M0, int N0, const int *rows0, const int *cols0, double eps, int reqrank, bool swp, std::vector<T> &Uout, std::vector<T> &Vout) {
+    const int M = swp ? N0 : M0, N = swp ? M0 : N0; // sizes of the matrix the algorithm sees
+    std::vector<T> U, V;
     std::vector<char> urow(M, 0), ucol(N, 0);
     std::vector<T> r(N), c(M);
+    // row I / column J of the matrix the algorithm sees, through the user's generator
+    auto get_row = [&](int I, T *out) { if (swp) g.fn(g.ctx, N, 1, rows0, cols0 + I, out); else g.fn(g.ctx, 1, N, rows0 + I, cols0, out); };
+    auto get_col = [&](int J, T *out) { if (swp) g.fn(g.ctx, 1, M, rows0 + J, cols0, out); else g.fn(g.ctx, M, 1, rows0, cols0 + J, out); };
     int k = 0, I = 0;
     double frob2 = 0;
     const int kmax = std::min(M, N);
+    int result = -2;
     while (k < kmax) {
         if (reqrank >= 0 && k >= reqrank) break;
-        g.fn(g.ctx, 1, N, rows + I, cols, r.data());
+        get_row(I, r.data());
         for (int l = 0; l < k; l++) {
             T u = U[(size_t)l * M + I];
             const T *v = &V[(size_t)l * N];
@@ -62,7 +69,7 @@ int host_aca(const Generator &g, int M, int N, const int *rows, const int *cols,
             continue;
         }
         T piv = r[J];
-        g.fn(g.ctx, M, 1, rows, cols + J, c.data());
+        get_col(J, c.data());
         for (int l = 0; l < k; l++) {
             T v = V[(size_t)l * N + J];
             const T *u = &U[(size_t)l * M];
@@ -86,7 +93,7 @@ int host_aca(const Generator &g, int M, int N, const int *rows, const int *cols,
         U.insert(U.end(), c.begin(), c.end());
         V.insert(V.end(), r.begin(), r.end());
         k++;
-        if ((int64_t)k * (M + N) > (int64_t)M * N) return -1;
+        if ((int64_t)k * (M + N) > (int64_t)M * N) { result = -1; break; }
         if (reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0))) break;
         int nI = -1;
         double bc = -1;
@@ -98,6 +105,9 @@ int host_aca(const Generator &g, int M, int N, const int *rows, const int *cols,
         if (nI < 0) break;
         I = nI;
     }
+    if (result == -1) return -1;
+    if (swp) { Uout.swap(V); Vout.swap(U); } // A = B^T = (U_B V_B)^T: U = V_B^T ([k][i] layout is V_B's), V = U_B^T
+    else { Uout.swap(U); Vout.swap(V); }
     return k;
 }
 
@@ -129,7 +139,7 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
                     for (int k = 0; k < r; k++) V[(size_t)k * b.n + j] = vv[(size_t)j * r + k];
             }
         } else {
-            rank = host_aca<T>(g, b.m, b.n, rows, cols, P.epsilon, P.reqrank, U, V);
+            rank = host_aca<T>(g, b.m, b.n, rows, cols, P.epsilon, P.reqrank, b.t_off > b.s_off, U, V);
         }
         if (rank < 0) {
             split_failed_block(Tt, Ss, P, b, adm, dns);

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <memory>
 #include <sstream>
+#include <cmath>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -19,6 +20,8 @@ struct htool_generator {
 struct htool_hmatrix {
     HMatrix H;
     ClusterHandle *tch = nullptr, *sch = nullptr;
+    void *factor = nullptr; // DenseFactor of the host fallback for lu/cholesky (capi.cpp)
+    ~htool_hmatrix();
 };
 struct htool_distributed {
     htool_hmatrix *hmat = nullptr;
@@ -304,31 +307,160 @@ int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void 
     API_END
 }
 
-int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering) {
-    API_BEGIN
-    // dense(H) = H * I, one product per column (test-sized operators only: O(N^2) output)
-    const HMatrix &H = h->H;
+} // extern "C"
+
+static void densify(const HMatrix &H, void *out, int user_numbering) {
+    // dense(H) = H * I, 64 unit vectors per call (8 sweeps of 8 right-hand sides); test-sized operators only
     const size_t es = H.is_complex ? 16 : 8;
     const int ns = H.sc->n_points;
     const size_t nr = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
-    std::vector<char> e((size_t)ns * es, 0), col(nr * es);
+    const int BS = 64;
+    std::vector<char> e((size_t)ns * BS * es, 0), col(nr * BS * es);
     const double one = 1.0, zero = 0.0;
-    for (int j = 0; j < ns; j++) {
-        // unit vector in user numbering that selects cluster column j (or user column j)
-        int uj = user_numbering ? j : H.sc->perm[j];
-        std::memcpy(&e[(size_t)uj * es], &one, sizeof(double));
-        device_matvec_host(H, e.data(), col.data());
-        std::memcpy(&e[(size_t)uj * es], &zero, sizeof(double));
-        char *dst = (char *)out + (size_t)j * nr * es;
-        if (user_numbering || H.t_root != 0) {
-            std::memcpy(dst, col.data(), nr * es);
-        } else {
-            for (size_t i = 0; i < nr; i++) std::memcpy(dst + i * es, &col[(size_t)H.tc->perm[i] * es], es);
+    for (int j0 = 0; j0 < ns; j0 += BS) {
+        const int nb = std::min(BS, ns - j0);
+        for (int j = 0; j < nb; j++) { // unit vector in user numbering selecting cluster (or user) column j0+j
+            int uj = user_numbering ? j0 + j : H.sc->perm[j0 + j];
+            std::memcpy(&e[((size_t)j * ns + uj) * es], &one, sizeof(double));
+        }
+        device_matmat_host(H, e.data(), nb, col.data());
+        for (int j = 0; j < nb; j++) {
+            int uj = user_numbering ? j0 + j : H.sc->perm[j0 + j];
+            std::memcpy(&e[((size_t)j * ns + uj) * es], &zero, sizeof(double));
+            char *dst = (char *)out + (size_t)(j0 + j) * nr * es;
+            const char *src = &col[(size_t)j * nr * es];
+            if (user_numbering || H.t_root != 0) std::memcpy(dst, src, nr * es);
+            else for (size_t i = 0; i < nr; i++) std::memcpy(dst + i * es, src + (size_t)H.tc->perm[i] * es, es);
         }
     }
+}
+
+// ---- dense host fallbacks for H-LU / H-Cholesky ------------------------------------
+// The reference factorises the H-matrix hierarchically (src/htool/hmatrix/hmatrix.hpp:58-94 ->
+// htool::lu_factorization / cholesky_factorization / lu_solve / cholesky_solve).  That is outside the
+// accelerated path; so that code written against the reference still runs, small operators are
+// densified (GPU products with unit vectors) and factorised on the host with partial pivoting.
+struct DenseFactor {
+    int kind = 0; // 1 LU, 2 Cholesky
+    char uplo = 'L';
+    int n = 0;
+    std::vector<double> ar; // real storage (column-major, user numbering)
+    std::vector<cplx> ac;
+    std::vector<int> piv;
+};
+
+template <typename T>
+static void lu_factor(int n, std::vector<T> &a, std::vector<int> &piv) {
+    piv.resize(n);
+    for (int k = 0; k < n; k++) {
+        int p = k;
+        double best = std::abs(a[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; i++) { double v = std::abs(a[(size_t)k * n + i]); if (v > best) best = v, p = i; }
+        HM_CHECK(best > 0, "lu_factorization: singular matrix");
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < n; j++) std::swap(a[(size_t)j * n + k], a[(size_t)j * n + p]);
+        const T inv = T(1) / a[(size_t)k * n + k];
+        for (int i = k + 1; i < n; i++) a[(size_t)k * n + i] *= inv;
+#pragma omp parallel for schedule(static)
+        for (int j = k + 1; j < n; j++) {
+            const T akj = a[(size_t)j * n + k];
+            if (akj == T(0)) continue;
+            T *cj = &a[(size_t)j * n];
+            const T *ck = &a[(size_t)k * n];
+            for (int i = k + 1; i < n; i++) cj[i] -= ck[i] * akj;
+        }
+    }
+}
+template <typename T>
+static void lu_solve_cols(int n, const std::vector<T> &a, const std::vector<int> &piv, char trans, T *b, int mu) {
+    for (int c = 0; c < mu; c++) {
+        T *x = b + (size_t)c * n;
+        if (trans == 'N') {
+            for (int k = 0; k < n; k++) if (piv[k] != k) std::swap(x[k], x[piv[k]]);
+            for (int k = 0; k < n; k++) for (int i = k + 1; i < n; i++) x[i] -= a[(size_t)k * n + i] * x[k];
+            for (int k = n - 1; k >= 0; k--) { x[k] /= a[(size_t)k * n + k]; for (int i = 0; i < k; i++) x[i] -= a[(size_t)k * n + i] * x[k]; }
+        } else { // A^T x = b: U^T, then L^T, then the inverse permutation
+            for (int k = 0; k < n; k++) { T s = x[k]; for (int i = 0; i < k; i++) s -= a[(size_t)k * n + i] * x[i]; x[k] = s / a[(size_t)k * n + k]; }
+            for (int k = n - 1; k >= 0; k--) { T s = x[k]; for (int i = k + 1; i < n; i++) s -= a[(size_t)k * n + i] * x[i]; x[k] = s; }
+            for (int k = n - 1; k >= 0; k--) if (piv[k] != k) std::swap(x[k], x[piv[k]]);
+        }
+    }
+}
+template <typename T>
+static void chol_factor(int n, std::vector<T> &a, char uplo) { // lower factor L stored in the lower triangle (A = L L^H)
+    if (uplo == 'U') // use the upper triangle as the data: mirror it down
+        for (int j = 0; j < n; j++) for (int i = j + 1; i < n; i++) a[(size_t)j * n + i] = a[(size_t)i * n + j];
+    for (int k = 0; k < n; k++) {
+        double d = std::real(cplx(a[(size_t)k * n + k]));
+        HM_CHECK(d > 0, "cholesky_factorization: matrix is not positive definite");
+        const double l = std::sqrt(d);
+        a[(size_t)k * n + k] = l;
+        for (int i = k + 1; i < n; i++) a[(size_t)k * n + i] /= l;
+#pragma omp parallel for schedule(static)
+        for (int j = k + 1; j < n; j++) {
+            const T ljk = a[(size_t)k * n + j];
+            T *cjp = &a[(size_t)j * n];
+            const T *ck = &a[(size_t)k * n];
+            for (int i = j; i < n; i++) cjp[i] -= ck[i] * ljk; // real symmetric / complex symmetric-as-stored
+        }
+    }
+}
+template <typename T>
+static void chol_solve_cols(int n, const std::vector<T> &a, T *b, int mu) {
+    for (int c = 0; c < mu; c++) {
+        T *x = b + (size_t)c * n;
+        for (int k = 0; k < n; k++) { x[k] /= a[(size_t)k * n + k]; for (int i = k + 1; i < n; i++) x[i] -= a[(size_t)k * n + i] * x[k]; }
+        for (int k = n - 1; k >= 0; k--) { T s = x[k]; for (int i = k + 1; i < n; i++) s -= a[(size_t)k * n + i] * x[i]; x[k] = s / a[(size_t)k * n + k]; }
+    }
+}
+
+extern "C" {
+int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering) {
+    API_BEGIN
+    densify(h->H, out, user_numbering);
     API_END
 }
 
+static DenseFactor *factor_of(htool_hmatrix *h, int kind, char uplo) {
+    const HMatrix &H = h->H;
+    HM_CHECK(H.t_root == 0 && H.tc->n_points == H.sc->n_points, "factorization needs a square H-matrix built on the whole clusters");
+    const int n = H.tc->n_points;
+    HM_CHECK(n <= 20000, "factorization: the dense host fallback is limited to 20000 unknowns (hierarchical LU is outside the MI355X hot path)");
+    log_message(LOG_WARNING, strprintf("%s: outside the accelerated path -- densifying %d x %d on the GPU and factorising on the host (O(N^3))", kind == 1 ? "lu_factorization" : "cholesky_factorization", n, n));
+    std::unique_ptr<DenseFactor> f(new DenseFactor);
+    f->kind = kind; f->uplo = uplo; f->n = n;
+    if (H.is_complex) { f->ac.resize((size_t)n * n); densify(H, f->ac.data(), 1); if (kind == 1) lu_factor(n, f->ac, f->piv); else chol_factor(n, f->ac, uplo); }
+    else { f->ar.resize((size_t)n * n); densify(H, f->ar.data(), 1); if (kind == 1) lu_factor(n, f->ar, f->piv); else chol_factor(n, f->ar, uplo); }
+    return f.release();
+}
+int htool_hmatrix_lu_factorization(htool_hmatrix *h) {
+    API_BEGIN
+    DenseFactor *f = factor_of(h, 1, 'N');
+    delete (DenseFactor *)h->factor;
+    h->factor = f;
+    API_END
+}
+int htool_hmatrix_cholesky_factorization(htool_hmatrix *h, char uplo) {
+    API_BEGIN
+    HM_CHECK(uplo == 'L' || uplo == 'U', "UPLO must be 'L' or 'U'");
+    HM_CHECK(!h->H.is_complex, "cholesky_factorization: complex operators are not supported by the dense host fallback");
+    DenseFactor *f = factor_of(h, 2, uplo);
+    delete (DenseFactor *)h->factor;
+    h->factor = f;
+    API_END
+}
+int htool_hmatrix_factor_solve(const htool_hmatrix *h, int kind, char trans, void *B, int mu) {
+    API_BEGIN
+    const DenseFactor *f = (const DenseFactor *)h->factor;
+    HM_CHECK(f != nullptr && f->kind == kind, kind == 1 ? "lu_solve: call lu_factorization first" : "cholesky_solve: call cholesky_factorization first");
+    HM_CHECK(trans == 'N' || trans == 'T', "factor solve: trans must be 'N' or 'T'");
+    if (kind == 1) { if (h->H.is_complex) lu_solve_cols<cplx>(f->n, f->ac, f->piv, trans, (cplx *)B, mu); else lu_solve_cols<double>(f->n, f->ar, f->piv, trans, (double *)B, mu); }
+    else chol_solve_cols<double>(f->n, f->ar, (double *)B, mu);
+    API_END
+}
+} // extern "C"
+
+extern "C" {
 int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
                             int target_partition_number, int64_t *n_admissible, int64_t *n_dense, int *admissible4, int *dense4) {
     API_BEGIN
@@ -366,6 +498,9 @@ int htool_cluster_tiles(const htool_cluster *root, int partition_number, int til
     return ts.count();
 }
 
+} // extern "C"
+htool_hmatrix::~htool_hmatrix() { delete (DenseFactor *)factor; }
+extern "C" {
 int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.blocks.size(); }
 void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5) {
     for (size_t i = 0; i < h->H.blocks.size(); i++) {

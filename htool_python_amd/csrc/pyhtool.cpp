@@ -424,10 +424,27 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("get_distributed_information", [](const H &s, py::object) { return parse_info(s.h, 1); })
         .def("get_target_cluster", [](const H &s) { return PyCluster{s.target.owner, htool_hmatrix_target_cluster(s.h)}; })
         .def("get_source_cluster", [](const H &s) { return PyCluster{s.source.owner, htool_hmatrix_source_cluster(s.h)}; })
-        .def("lu_factorization", [](H &) { throw std::runtime_error("H-LU factorization is outside the MI355X hot path (build + product); not implemented"); })
-        .def("cholesky_factorization", [](H &, char) { throw std::runtime_error("H-Cholesky factorization is outside the MI355X hot path (build + product); not implemented"); })
-        .def("lu_solve", [](const H &, char, py::object) -> py::object { throw std::runtime_error("H-LU solve is outside the MI355X hot path (build + product); not implemented"); })
-        .def("cholesky_solve", [](const H &, char, py::object) -> py::object { throw std::runtime_error("H-Cholesky solve is outside the MI355X hot path (build + product); not implemented"); })
+        .def("lu_factorization", [](H &s) { check(htool_hmatrix_lu_factorization(s.h)); })
+        .def("cholesky_factorization", [](H &s, char UPLO) { check(htool_hmatrix_cholesky_factorization(s.h, UPLO)); })
+        .def("lu_solve", [](const H &s, char trans, const py::array_t<T, py::array::f_style> &input) {
+                if (input.ndim() != 1 && input.ndim() != 2) throw std::runtime_error("Wrong dimension for HMatrix-LU input");
+                py::array_t<T, py::array::f_style> result = input.ndim() == 1 ? py::array_t<T, py::array::f_style>(input.shape(0))
+                                                                             : py::array_t<T, py::array::f_style>({input.shape(0), input.shape(1)});
+                std::copy_n(input.data(), input.size(), result.mutable_data());
+                if (input.shape(0) != htool_hmatrix_nb_rows(s.h)) throw std::runtime_error("Wrong size for HMatrix-LU input");
+                check(htool_hmatrix_factor_solve(s.h, 1, trans, result.mutable_data(), input.ndim() == 1 ? 1 : (int)input.shape(1)));
+                return result;
+            })
+        .def("cholesky_solve", [](const H &s, char UPLO, const py::array_t<T, py::array::f_style> &input) {
+                if (input.ndim() != 1 && input.ndim() != 2) throw std::runtime_error("Wrong dimension for HMatrix-Cholesky input");
+                py::array_t<T, py::array::f_style> result = input.ndim() == 1 ? py::array_t<T, py::array::f_style>(input.shape(0))
+                                                                             : py::array_t<T, py::array::f_style>({input.shape(0), input.shape(1)});
+                std::copy_n(input.data(), input.size(), result.mutable_data());
+                if (input.shape(0) != htool_hmatrix_nb_rows(s.h)) throw std::runtime_error("Wrong size for HMatrix-Cholesky input");
+                (void)UPLO;
+                check(htool_hmatrix_factor_solve(s.h, 2, 'N', result.mutable_data(), input.ndim() == 1 ? 1 : (int)input.shape(1)));
+                return result;
+            })
         .def("__mul__", &H::mul, "in"_a)
         .def("__matmul__", &H::matmul, "in"_a)
         // extensions used by tests / bench: flattened leaf table, leaf panels, statistics

@@ -143,6 +143,14 @@ int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64
 /* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
 int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);
 
+/* H-LU / H-Cholesky (hmatrix.hpp:58-94) are OUTSIDE the accelerated path.  So that code written for the
+ * reference still runs, these entries densify the operator with GPU products and factorise it on the host
+ * (partial pivoting, O(N^3), at most 20000 unknowns; a WARNING is logged).  kind: 1 = LU, 2 = Cholesky;
+ * B is n x mu column-major in user numbering, overwritten by the solution. */
+int htool_hmatrix_lu_factorization(htool_hmatrix *h);
+int htool_hmatrix_cholesky_factorization(htool_hmatrix *h, char uplo);
+int htool_hmatrix_factor_solve(const htool_hmatrix *h, int kind, char trans, void *B, int mu);
+
 /* host-only introspection (needs no GPU): the two work queues of the block cluster tree BEFORE the
  * leaves are filled -- admissible (to be compressed) and inadmissible (dense) -- as 4 ints per entry
  * {t_off, m, s_off, n}.  Call with NULL arrays to get the counts.  (hmatrix_tree_builder.hpp:36) */

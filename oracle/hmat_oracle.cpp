@@ -302,17 +302,24 @@ static inline double re(const cplx &x) { return x.real(); }
 // U is stored column-major m x r; V is stored row-major by step, i.e. Vt[k*n + j] = V(k,j).
 // returns rank, or -1 on failure.
 // ---------------------------------------------------------------------------
+// swp = "sym" role rule: leaves below the diagonal (t_off > s_off) are compressed through their transpose so
+// that a symmetric kernel yields exactly transposed factors for the leaves (t,s) and (s,t).
 template <typename T>
-static int aca(const Gen &g, int M, int N, const int *rows, const int *cols, double eps, int reqrank, std::vector<T> &U, std::vector<T> &V) {
-    U.clear(); V.clear();
+static int aca(const Gen &g, int M0, int N0, const int *rows0, const int *cols0, double eps, int reqrank, std::vector<T> &Uout, std::vector<T> &Vout, bool swp = false) {
+    const int M = swp ? N0 : M0, N = swp ? M0 : N0;
+    std::vector<T> U, V;
+    Uout.clear(); Vout.clear();
     std::vector<char> urow(M, 0), ucol(N, 0);
     std::vector<T> r(N), c(M);
+    // entry (I, J) of the matrix the algorithm sees
+    auto entry = [&](int I, int J, T &a) { if (swp) g.eval(rows0[J], cols0[I], a); else g.eval(rows0[I], cols0[J], a); };
     int k = 0, I = 0;
     double frob2 = 0;
     const int kmax = std::min(M, N);
+    bool failed = false;
     while (k < kmax) {
         if (reqrank >= 0 && k >= reqrank) break;
-        for (int j = 0; j < N; j++) { T a; g.eval(rows[I], cols[j], a); r[j] = a; }
+        for (int j = 0; j < N; j++) { T a; entry(I, j, a); r[j] = a; }
         for (int l = 0; l < k; l++) { T u = U[(size_t)l * M + I]; const T *v = &V[(size_t)l * N]; for (int j = 0; j < N; j++) r[j] -= u * v[j]; }
         urow[I] = 1;
         int J = -1; double best = -1;
@@ -325,7 +332,7 @@ static int aca(const Gen &g, int M, int N, const int *rows, const int *cols, dou
             I = nI; continue;
         }
         T piv = r[J];
-        for (int i = 0; i < M; i++) { T a; g.eval(rows[i], cols[J], a); c[i] = a; }
+        for (int i = 0; i < M; i++) { T a; entry(i, J, a); c[i] = a; }
         for (int l = 0; l < k; l++) { T v = V[(size_t)l * N + J]; const T *u = &U[(size_t)l * M]; for (int i = 0; i < M; i++) c[i] -= v * u[i]; }
         T inv = T(1) / piv;
         for (int i = 0; i < M; i++) c[i] *= inv;
@@ -345,14 +352,15 @@ static int aca(const Gen &g, int M, int N, const int *rows, const int *cols, dou
         U.insert(U.end(), c.begin(), c.end());
         V.insert(V.end(), r.begin(), r.end());
         k++;
-        if ((int64_t)k * (M + N) > (int64_t)M * N) return -1;
+        if ((int64_t)k * (M + N) > (int64_t)M * N) { failed = true; break; }
         if (reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0))) break;
         int nI = -1; double bc = -1;
         for (int i = 0; i < M; i++) if (!urow[i]) { double a = abs2(c[i]); if (a > bc) { bc = a; nI = i; } }
         if (nI < 0) break;
         I = nI;
     }
-    if (reqrank < 0 && k == kmax && (int64_t)k * (M + N) > (int64_t)M * N) return -1;
+    if (failed) return -1;
+    if (swp) { Uout.swap(V); Vout.swap(U); } else { Uout.swap(U); Vout.swap(V); }
     return k;
 }
 
@@ -376,7 +384,7 @@ static void fill_block(const Gen &g, const ClusterTree &T_, const ClusterTree &S
     const int *rows = &T_.perm[nt.offset], *cols = &S_.perm[ns.offset];
     if (try_lr) {
         Leaf<T> L; L.t_off = nt.offset; L.m = nt.size; L.s_off = ns.offset; L.n = ns.size;
-        int r = aca<T>(g, nt.size, ns.size, rows, cols, eps, reqrank, L.U, L.V);
+        int r = aca<T>(g, nt.size, ns.size, rows, cols, eps, reqrank, L.U, L.V, nt.offset > ns.offset);
         if (r >= 0) { L.rank = r; out.push_back(std::move(L)); return; }
         // compression failed: treat as non-admissible, dig deeper
         std::vector<Block> adm, dns;

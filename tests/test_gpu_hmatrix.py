@@ -60,6 +60,22 @@ def test_hmatrix_reference_case(built, oracle, symmetry, custom_svd):
     assert np.linalg.norm(Y - dense_user @ X) / np.linalg.norm(dense_user @ X) < 1e-10
     assert np.linalg.norm(Y - copy_hmatrix @ X) < 1e-10
 
+    if symmetry != "N":
+        # H-LU / H-Cholesky solves (tests/test_hmatrix.py:98-128); served by the dense host fallback
+        copy_hmatrix.lu_factorization()
+        x_ref = np.ones(nb_cols)
+        x_lu = copy_hmatrix.lu_solve("N", hmatrix * x_ref)
+        assert np.linalg.norm(x_lu - x_ref) / np.linalg.norm(x_ref) < epsilon
+        x_ref2 = np.ones((nb_cols, 2))
+        x_lu2 = copy_hmatrix.lu_solve("N", hmatrix @ x_ref2)
+        assert np.linalg.norm(x_lu2 - x_ref2) / np.linalg.norm(x_ref2) < epsilon
+        copy_hmatrix = copy.deepcopy(hmatrix)
+        copy_hmatrix.cholesky_factorization("L")
+        x_ch = copy_hmatrix.cholesky_solve("L", hmatrix * x_ref)
+        assert np.linalg.norm(x_ch - x_ref) / np.linalg.norm(x_ref) < epsilon
+        x_ch2 = copy_hmatrix.cholesky_solve("L", hmatrix @ x_ref2)
+        assert np.linalg.norm(x_ch2 - x_ref2) / np.linalg.norm(x_ref2) < epsilon
+
     # densified in cluster numbering == permuted user-numbered one
     pt, ps = np.asarray(target_cluster.get_permutation()), np.asarray(source_cluster.get_permutation())
     assert np.allclose(hmatrix.to_dense(), dense_user[np.ix_(pt, ps)], rtol=0, atol=1e-13)

@@ -169,3 +169,44 @@ def test_full_size_configs_by_properties(built, oracle, n, eps, kind, p0, leaf):
         exact = O.kernel_block(kind, pts[:, perm[t_off:t_off + m]], pts[:, perm[s_off:s_off + nn]], p0)
         # partial-pivot ACA stops on a heuristic estimate: a single leaf may miss eps by a small factor
         assert np.linalg.norm(blk - exact) <= 20 * eps * np.linalg.norm(exact)
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_symmetric_operator_is_exactly_symmetric(built, oracle, native):
+    """"sym" role rule of the ACA (leaves below the diagonal are compressed through their transpose): for a
+    symmetric kernel on one cluster tree the leaves (t,s) and (s,t) carry exactly transposed factors, so the
+    H-matrix is symmetric bit for bit, and the engine (which stores both triangles) agrees to rounding with
+    the oracle's one-triangle storage ('S','L' and 'S','U') that applies stored leaves transposed."""
+    import Htool
+    from tests.helpers import NumpyGenerator, cluster_of
+
+    O = oracle
+    n = 1500
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 16)
+    gen = Htool.NativeGenerator("inv_delta", pts, pts, 0.1) if native else NumpyGenerator(pts, pts)
+    for sym, uplo in (("N", "N"), ("S", "L"), ("S", "U")):
+        H = Htool.HMatrixTreeBuilder(1e-5, 10.0, sym, uplo).build(gen, cl, cl)
+        L = np.asarray(H.leaves())
+        index = {tuple(l[:4]): i for i, l in enumerate(L)}
+        pairs = [(i, index[(l[2], l[3], l[0], l[1])]) for i, l in enumerate(L) if l[0] > l[2]]
+        assert len(pairs) > 50
+        rng = np.random.RandomState(0)
+        for i, j in [pairs[q] for q in rng.choice(len(pairs), 40, replace=False)]:
+            assert L[i, 4] == L[j, 4]
+            A1, B1 = H.leaf_panels(int(i))
+            A2, B2 = H.leaf_panels(int(j))
+            if L[i, 4] < 0:
+                assert np.array_equal(np.asarray(A1), np.asarray(A2).T)  # dense leaves: same entries
+            else:
+                assert np.array_equal(np.asarray(A1), np.asarray(B2).T) and np.array_equal(np.asarray(B1), np.asarray(A2).T)
+        # the densified operator is symmetric up to the summation order of the product kernel
+        D = H.to_dense_in_user_numbering()
+        assert np.abs(D - D.T).max() <= 1e-14 * np.abs(D).max()
+    oc = O.Cluster(pts, max_leaf=16)
+    x = np.random.rand(n)
+    y = H * x
+    for uplo in ("L", "U"):
+        OH = O.HMatrix(oc, oc, O.K_INV_DELTA, 0.1, eps=1e-5, eta=10.0, symmetry="S", uplo=uplo)
+        assert np.linalg.norm(y - OH.matvec(x)) / np.linalg.norm(y) < 1e-12
