@@ -81,10 +81,10 @@ void visit(const Ctx &c, int t, int s) {
 
 } // namespace
 
-void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int /*sym_partition*/,
+void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int s_root,
                       std::vector<BlockRec> &adm, std::vector<BlockRec> &dns) {
     Ctx c{T, S, P, adm, dns};
-    visit(c, t_root, 0);
+    visit(c, t_root, s_root < 0 ? 0 : s_root);
 }
 
 void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, const BlockRec &b,

@@ -118,7 +118,7 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
     const ClusterTree &Tt = *H.tc, &Ss = *H.sc;
     const BuildParams &P = H.params;
     std::vector<BlockRec> adm, dns, done;
-    build_block_tree(Tt, Ss, P, H.t_root, -1, adm, dns);
+    build_block_tree(Tt, Ss, P, H.t_root, H.s_root, adm, dns);
     arena.clear();
     std::vector<T> U, V;
     // low-rank queue; failures are re-split and appended to the queues

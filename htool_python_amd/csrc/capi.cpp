@@ -25,6 +25,7 @@ struct htool_hmatrix {
 };
 struct htool_distributed {
     htool_hmatrix *hmat = nullptr;
+    htool_hmatrix *block_diag = nullptr; // (partition rank x partition rank) sub-operator; aliases hmat for one rank
     htool_comm comm;
     const ClusterTree *tc = nullptr, *sc = nullptr;
     std::vector<int64_t> counts, displs; // rows per rank / first row per rank (cluster numbering)
@@ -163,7 +164,7 @@ void htool_build_params_default(htool_build_params *p) {
 
 // ---- H-matrix ----------------------------------------------------------------------------------
 static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
-                                    const htool_build_params *params, int target_partition) {
+                                    const htool_build_params *params, int target_partition, int source_partition = -1) {
     HM_CHECK(g && target_root && source_root && params, "htool_hmatrix_build: null argument");
     ClusterTree *T = CH(target_root)->tree, *S = CH(source_root)->tree;
     HM_CHECK(params->symmetry == 'N' || params->symmetry == 'S' || params->symmetry == 'H', "symmetry must be 'N', 'S' or 'H'");
@@ -198,11 +199,18 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     }
     H.row_off = T->offset[H.t_root];
     H.row_size = T->size[H.t_root];
+    H.s_root = 0;
+    if (source_partition >= 0) {
+        HM_CHECK(source_partition < (int)S->part_nodes.size(), "source partition number out of range");
+        H.s_root = S->part_nodes[source_partition];
+    }
+    H.col_off = S->offset[H.s_root];
+    H.col_size = S->size[H.s_root];
     H.tile_max = H.is_complex ? 64 : 128;
     H.rtiles = make_tiles(*T, H.t_root, H.tile_max);
-    H.ctiles = make_tiles(*S, 0, H.tile_max);
+    H.ctiles = make_tiles(*S, H.s_root, H.tile_max);
     h->tch = T->handle(H.t_root);
-    h->sch = S->handle(0);
+    h->sch = S->handle(H.s_root);
     double t0 = wall_seconds();
     if (g->g.native) {
         device_build_native(H, g->g);
@@ -226,6 +234,12 @@ int htool_hmatrix_build(const htool_generator *g, const htool_cluster *target_ro
     *out = build_hmatrix(g, target_root, source_root, params, target_partition_number);
     API_END
 }
+int htool_hmatrix_build_local(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
+                              int target_partition_number, int source_partition_number, htool_hmatrix **out) {
+    API_BEGIN
+    *out = build_hmatrix(g, target_root, source_root, params, target_partition_number, source_partition_number);
+    API_END
+}
 void htool_hmatrix_destroy(htool_hmatrix *h) { delete h; }
 int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     API_BEGIN
@@ -233,6 +247,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     const HMatrix &s = h->H;
     HMatrix &d = c->H;
     d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
+    d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size;
     d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.blocks = s.blocks; d.r_elems = s.r_elems;
     d.build_seconds = s.build_seconds; d.n_batches = s.n_batches;
     c->tch = h->tch; c->sch = h->sch;
@@ -242,7 +257,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
 }
 int htool_hmatrix_is_complex(const htool_hmatrix *h) { return h->H.is_complex ? 1 : 0; }
 int htool_hmatrix_nb_rows(const htool_hmatrix *h) { return h->H.row_size; }
-int htool_hmatrix_nb_cols(const htool_hmatrix *h) { return h->H.sc->n_points; }
+int htool_hmatrix_nb_cols(const htool_hmatrix *h) { return h->H.col_size; }
 const htool_cluster *htool_hmatrix_target_cluster(const htool_hmatrix *h) { return reinterpret_cast<const htool_cluster *>(h->tch); }
 const htool_cluster *htool_hmatrix_source_cluster(const htool_hmatrix *h) { return reinterpret_cast<const htool_cluster *>(h->sch); }
 
@@ -251,6 +266,13 @@ const htool_cluster *htool_hmatrix_source_cluster(const htool_hmatrix *h) { retu
 template <typename T>
 static void axpby(size_t n, T alpha, const T *t, T beta, T *y) {
     for (size_t i = 0; i < n; i++) y[i] = alpha * t[i] + (beta == T(0) ? T(0) : beta * y[i]);
+}
+
+static void check_numbering(const HMatrix &H, int numbering) {
+    HM_CHECK(numbering >= 0 && numbering <= 3, "numbering must be 0 (user/user), 1 (cluster/cluster), 2 (user in, cluster out) or 3 (cluster in, user out)");
+    const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
+    HM_CHECK(!out_user || H.t_root == 0, "user-numbered output needs an H-matrix built on the whole target cluster");
+    HM_CHECK(!in_user || H.s_root == 0, "user-numbered input needs an H-matrix built on the whole source cluster");
 }
 
 static void matvec_scaled(const HMatrix &H, const void *alpha, const void *x, const void *beta, void *y) {
@@ -283,7 +305,7 @@ int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, 
     HM_CHECK(trans == 'N', "H-matrix product: only trans='N' is implemented on the HIP path");
     const HMatrix &H = h->H;
     const size_t es = H.is_complex ? 16 : 8;
-    const size_t nin = (size_t)H.sc->n_points, nout = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+    const size_t nin = (size_t)H.col_size, nout = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
     bool plain;
     if (H.is_complex) plain = (!alpha || *(const cplx *)alpha == cplx(1)) && (!beta || *(const cplx *)beta == cplx(0));
     else plain = (!alpha || *(const double *)alpha == 1.0) && (!beta || *(const double *)beta == 0.0);
@@ -293,16 +315,14 @@ int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, 
 }
 int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream) {
     API_BEGIN
-    HM_CHECK(numbering >= 0 && numbering <= 2, "numbering must be 0 (user), 1 (cluster) or 2 (user in, cluster out)");
-    HM_CHECK(numbering != 0 || h->H.t_root == 0, "user-numbered output needs an H-matrix built on the whole target cluster");
+    check_numbering(h->H, numbering);
     HM_CHECK(mu >= 1, "mu must be >= 1");
     device_matmat_device(h->H, X_dev, (long long)ldx, Y_dev, (long long)ldy, mu, numbering, stream);
     API_END
 }
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream) {
     API_BEGIN
-    HM_CHECK(numbering >= 0 && numbering <= 2, "numbering must be 0 (user), 1 (cluster) or 2 (user in, cluster out)");
-    HM_CHECK(numbering != 0 || h->H.t_root == 0, "user-numbered output needs an H-matrix built on the whole target cluster");
+    check_numbering(h->H, numbering);
     device_matvec_device(h->H, x_dev, y_dev, numbering, stream);
     API_END
 }
@@ -312,9 +332,10 @@ int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void 
 static void densify(const HMatrix &H, void *out, int user_numbering) {
     // dense(H) = H * I, 64 unit vectors per call (8 sweeps of 8 right-hand sides); test-sized operators only
     const size_t es = H.is_complex ? 16 : 8;
-    const int ns = H.sc->n_points;
+    const int ns = H.col_size;
     const size_t nr = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
     const int BS = 64;
+    if (H.s_root != 0) user_numbering = 1; // local columns: the input side is the local slice in cluster order already
     std::vector<char> e((size_t)ns * BS * es, 0), col(nr * BS * es);
     const double one = 1.0, zero = 0.0;
     for (int j0 = 0; j0 < ns; j0 += BS) {
@@ -478,7 +499,7 @@ int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluste
         t_root = T->part_nodes[target_partition_number];
     }
     std::vector<BlockRec> adm, dns;
-    build_block_tree(*T, *S, P, t_root, -1, adm, dns);
+    build_block_tree(*T, *S, P, t_root, 0, adm, dns);
     if (n_admissible) *n_admissible = (int64_t)adm.size();
     if (n_dense) *n_dense = (int64_t)dns.size();
     auto fill = [](const std::vector<BlockRec> &v, int *out) {
@@ -548,7 +569,7 @@ int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap) {
             else { lmin = lmin < 0 ? sz : std::min(lmin, sz); lmax = std::max(lmax, sz); rmin = rmin < 0 ? b.rank : std::min<int64_t>(rmin, b.rank); rmean += b.rank; }
         }
         if (st[3]) rmean /= (double)st[3];
-        double full = (double)H.row_size * (double)H.sc->n_points;
+        double full = (double)H.row_size * (double)H.col_size;
         double cr = full > 0 ? (double)(st[0] + st[1]) / full : 0;
         o << "Number_of_dense_blocks=" << st[2] << "\nNumber_of_low_rank_blocks=" << st[3] << "\nDense_block_size_max=" << dmax << "\nDense_block_size_min=" << std::max<int64_t>(dmin, 0)
           << "\nLow_rank_block_size_max=" << lmax << "\nLow_rank_block_size_min=" << std::max<int64_t>(lmin, 0) << "\nRank_max=" << st[7] << "\nRank_min=" << std::max<int64_t>(rmin, 0)
@@ -579,15 +600,24 @@ int htool_distributed_create_default(const htool_generator *g, const htool_clust
         d->counts.push_back(T->size[T->part_nodes[p]]);
         d->displs.push_back(T->offset[T->part_nodes[p]]);
     }
-    d->hmat = build_hmatrix(g, target_root, source_root, params, comm->size == 1 && T->part_nodes[0] == 0 ? -1 : comm->rank);
+    const bool single = comm->size == 1 && T->part_nodes[0] == 0;
+    d->hmat = build_hmatrix(g, target_root, source_root, params, single ? -1 : comm->rank);
+    // block-diagonal part (distributed_operator/utility.hpp:31): needs the source tree to carry the same partition
+    const ClusterTree *S = CH(source_root)->tree;
+    if (single) d->block_diag = d->hmat;
+    else if ((int)S->part_nodes.size() == comm->size) d->block_diag = build_hmatrix(g, target_root, source_root, params, comm->rank, comm->rank);
     *out = d.release();
     API_END
 }
 void htool_distributed_destroy(htool_distributed *d) {
-    if (d) { delete d->hmat; delete d; }
+    if (d) {
+        if (d->block_diag != d->hmat) delete d->block_diag;
+        delete d->hmat;
+        delete d;
+    }
 }
 htool_hmatrix *htool_distributed_hmatrix(htool_distributed *d) { return d->hmat; }
-htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *) { return nullptr; }
+htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *d) { return d->block_diag; }
 void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols) {
     *rows = d->tc->n_points;
     *cols = d->sc->n_points;

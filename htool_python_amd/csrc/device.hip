@@ -296,6 +296,7 @@ struct PackArgs {
     int *index;                // cidxB / oidxA
     const void *arena;
     int vec_rows, tile_max;
+    int col_off;               // first source position covered by the H-matrix (coefficient indices are relative to it)
     int eval_dense;            // dense leaves are evaluated from gen instead of copied
     DevGen gen;
 };
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void pack_u_kernel(PackArgs a) {
         else if (b.rank < 0 && a.eval_dense) gen_eval(a.gen, toff + i, b.s_off + k, v);
         else v = src[(long long)k * b.m + i];
         dst[(long long)k * ld + i] = v;
-        if (i == 0) cidx[k] = b.rank >= 0 ? (int)(b.tpos + k) : b.s_off + k;
+        if (i == 0) cidx[k] = b.rank >= 0 ? (int)(b.tpos + k) : b.s_off - a.col_off + k;
     }
 }
 
@@ -447,7 +448,7 @@ struct DeviceBuilder {
         D->is_complex = H.is_complex;
         D->esize = H.is_complex ? 16 : 8;
         vec_rows = H.is_complex ? 1 : 2;
-        D->n_source = H.sc->n_points;
+        D->n_source = H.col_size;
         D->n_target = H.tc->n_points;
         D->row_off = H.row_off;
         D->row_size = H.row_size;
@@ -487,7 +488,7 @@ struct DeviceBuilder {
         std::vector<long long> t3(L.a_pbase.begin(), L.a_pbase.end()), t4(L.a_obase.begin(), L.a_obase.end());
         long long *d_bp = upload(t1), *d_bc = upload(t2), *d_ap = upload(t3), *d_ao = upload(t4);
         PackArgs a;
-        a.blocks = d_blocks; a.arena = d_arena; a.vec_rows = vec_rows; a.tile_max = H.tile_max;
+        a.blocks = d_blocks; a.arena = d_arena; a.vec_rows = vec_rows; a.tile_max = H.tile_max; a.col_off = H.col_off;
         a.eval_dense = eval_dense ? 1 : 0; a.gen = gen;
         // U / dense side
         a.item_block = d_ub; a.item_tile = d_ut; a.tile_off = d_rt_off; a.tile_size = d_rt_size; a.tile_n = d_bn;
@@ -514,7 +515,7 @@ struct DeviceBuilder {
     template <typename T>
     void assemble() {
         const ClusterTree &Tt = *H.tc, &Ss = *H.sc;
-        const int TM = H.tile_max, Ns = Ss.n_points;
+        const int TM = H.tile_max, Ns = H.col_size;
         std::vector<BatchTables> &tabs = D->tabs;
         const long long r_start = (Ns + 1 + 1) / 2 * 2;
         D->W_elems = (r_start + H.r_elems + 2 + 1) / 2 * 2; // even: every right-hand-side copy stays 16-byte aligned
@@ -525,7 +526,7 @@ struct DeviceBuilder {
         *(double *)&one = 1.0;
         HIP_OK(hipMemcpy((char *)D->W + (size_t)Ns * sizeof(T), &one, sizeof(T), hipMemcpyHostToDevice));
         D->rhs_cap = 1;
-        D->perm_s = upload(Ss.perm, &D->table_bytes);
+        D->perm_s = upload(std::vector<int>(Ss.perm.begin() + H.col_off, Ss.perm.begin() + H.col_off + H.col_size), &D->table_bytes);
         D->perm_t = upload(Tt.perm, &D->table_bytes);
         std::vector<int> io(Ns);
         std::iota(io.begin(), io.end(), 0);
@@ -580,7 +581,7 @@ struct DeviceBuilder {
                 int nq = (nr + TM - 1) / TM, rem = nr - (nq - 1) * TM;
                 GSeg s;
                 s.panel = (const char *)D->batches[b].panelA + (size_t)tabs[b].a_pbase[c] * sizeof(T);
-                s.cidx = D->iota + H.ctiles.off[c];
+                s.cidx = D->iota + (H.ctiles.off[c] - H.col_off);
                 s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.pad_ = 0;
                 s.chunk_stride = (long long)H.ctiles.size[c] * TM;
                 // cut tall tiles into pieces of at most qmax row chunks (independent outputs, no reduction)
@@ -699,9 +700,11 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     T *W = (T *)D->W;
     const int Ns = D->n_source;
     const long long ws = D->W_elems;
+    // numbering: 0 user in / user out, 1 cluster / cluster, 2 user / cluster, 3 cluster / user
+    const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
     hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
     HIP_OK(hipEventRecord(ev[0], st));
-    if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, x_stride, (numbering == 0 || numbering == 2) ? D->perm_s : (const int *)nullptr, W, ws, Ns, NR);
+    if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, x_stride, in_user ? D->perm_s : (const int *)nullptr, W, ws, Ns, NR);
     HIP_OK(hipEventRecord(ev[1], st));
     if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W, ws, ws, 0LL);
     HIP_OK(hipEventRecord(ev[2], st));
@@ -711,9 +714,9 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
         const long long ps = (long long)D->splitB * D->ypart_stride;
         hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, (T *)D->ypart, ws, ps);
         hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
-                           numbering == 0 ? D->perm_t + D->row_off : (const int *)nullptr, (T *)y_dev, y_stride, NR);
+                           out_user ? D->perm_t + D->row_off : (const int *)nullptr, (T *)y_dev, y_stride, NR);
     } else if (D->nB) {
-        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB), dim3(256), 0, st, numbering == 0 ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev, ws, y_stride);
+        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB), dim3(256), 0, st, out_user ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev, ws, y_stride);
     }
     HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
@@ -786,6 +789,13 @@ void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int 
     device_matmat_device(H, x_dev, 0, y_dev, 0, 1, numbering, stream);
 }
 
+// host API convention: a matrix built on the whole target (source) cluster takes/returns user numbering on
+// that side; one built on a partition works on its local slice in cluster order
+static int host_numbering(const HMatrix &H) {
+    const bool in_user = H.s_root == 0, out_user = H.t_root == 0;
+    return in_user ? (out_user ? 0 : 2) : (out_user ? 3 : 1);
+}
+
 void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
@@ -795,7 +805,7 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     // a matrix built on the whole target cluster answers in user numbering; one built on a partition
     // answers with its local rows in cluster order
     const bool whole = H.t_root == 0;
-    device_matvec_device(H, D->x_tmp, D->y_tmp, whole ? 0 : 2, D->stream);
+    device_matvec_device(H, D->x_tmp, D->y_tmp, host_numbering(H), D->stream);
     HIP_OK(hipMemcpyAsync(y, D->y_tmp, (size_t)(whole ? D->n_target : D->row_size) * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
 }
@@ -812,7 +822,7 @@ void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
     HIP_OK(hipMalloc(&dX, std::max<size_t>(nin * mu, 1) * es));
     HIP_OK(hipMalloc(&dY, std::max<size_t>(nout * mu, 1) * es));
     HIP_OK(hipMemcpyAsync(dX, X, nin * mu * es, hipMemcpyHostToDevice, D->stream));
-    device_matmat_device(H, dX, (long long)nin, dY, (long long)nout, mu, whole ? 0 : 2, D->stream);
+    device_matmat_device(H, dX, (long long)nin, dY, (long long)nout, mu, host_numbering(H), D->stream);
     HIP_OK(hipMemcpyAsync(Y, dY, nout * mu * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
     (void)hipFree(dX);

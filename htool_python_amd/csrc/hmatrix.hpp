@@ -98,6 +98,8 @@ struct HMatrix {
     const ClusterTree *tc = nullptr, *sc = nullptr;
     int t_root = 0;                 // target node the matrix was built on (root or a partition)
     int row_off = 0, row_size = 0;  // rows covered, cluster numbering
+    int s_root = 0;                 // source node (root, or a partition for block-diagonal / local operators)
+    int col_off = 0, col_size = 0;  // columns covered, cluster numbering
     bool is_complex = false;
     BuildParams params;
     int tile_max = 128;
@@ -111,7 +113,7 @@ struct HMatrix {
 };
 
 // ---- block tree (blocktree.cpp) ----
-void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int sym_partition,
+void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int s_root,
                       std::vector<BlockRec> &adm, std::vector<BlockRec> &dns);
 // sub-blocks of an admissible block whose compression failed (re-visit ignoring its own admissibility)
 void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, const BlockRec &b,

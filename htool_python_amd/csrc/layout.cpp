@@ -86,7 +86,7 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
     L.oidxA_elems = oa;
 
     // ---- region R of W: t vectors, and partial panels for source nodes spanning several tiles
-    const int64_t r_start = round_up(S.n_points + 1, 2); // W index of R[0]
+    const int64_t r_start = round_up(H.col_size + 1, 2); // W index of R[0]
     std::vector<int64_t> tb(ns, -1), pbse(ns, -1);
     std::vector<int> ldp(ns, 0);
     int64_t cur = H.r_elems;

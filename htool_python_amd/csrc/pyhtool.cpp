@@ -357,7 +357,7 @@ struct PyDefaultApproximationBuilder {
     std::shared_ptr<PyComm> comm;
     PyCluster target, source;
     PyDistributedOperator<T> op;
-    PyHMatrix<T> hmat;
+    PyHMatrix<T> hmat, bdiag;
     PyDefaultApproximationBuilder(PyIGenerator<T> &generator, const PyCluster &t, const PyCluster &s, const PyHMatrixTreeBuilder<T> &builder, py::object comm_obj)
         : comm(std::make_shared<PyComm>(comm_obj)), target(t), source(s) {
         htool_build_params q = builder.resolved();
@@ -369,6 +369,10 @@ struct PyDefaultApproximationBuilder {
         hmat.owned = false;
         hmat.target = t;
         hmat.source = s;
+        bdiag.h = htool_distributed_block_diagonal_hmatrix(d);
+        bdiag.owned = false;
+        bdiag.target = t;
+        bdiag.source = s;
     }
     ~PyDefaultApproximationBuilder() { htool_distributed_destroy(d); }
 };
@@ -507,6 +511,14 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                  return b;
              }), "epsilon"_a, "eta"_a, "symmetry"_a, "UPLO"_a, py::kw_only(), "reqrank"_a = -1, "low_rank_strategy"_a = py::none())
         .def("build", &B::build, "generator"_a, "target_cluster"_a, "source_cluster"_a, "target_partition_number"_a = -1, "partition_number_for_symmetry"_a = -1)
+        .def("build_local", [](const B &b, PyIGenerator<T> &generator, const PyCluster &target, const PyCluster &source, int target_partition_number, int source_partition_number) {
+                PyHMatrix<T> H;
+                H.target = target;
+                H.source = source;
+                htool_build_params q = b.resolved();
+                check(htool_hmatrix_build_local(generator.get(), target.owner->root, source.owner->root, &q, target_partition_number, source_partition_number, &H.h));
+                return H;
+            }, "generator"_a, "target_cluster"_a, "source_cluster"_a, "target_partition_number"_a, "source_partition_number"_a)
         .def("set_minimal_source_depth", [](B &b, int d) { b.p.minimal_source_depth = d; })
         .def("set_minimal_target_depth", [](B &b, int d) { b.p.minimal_target_depth = d; })
         .def("set_low_rank_generator", [](B &b, py::object g) { b.low_rank = g.cast<std::shared_ptr<PyVirtualLowRankGenerator<T>>>(); b.low_rank_ref = g; })
@@ -540,7 +552,7 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def(py::init<PyIGenerator<T> &, const PyCluster &, const PyCluster &, const B &, py::object>())
         .def_property_readonly("distributed_operator", [](DA &s) { return &s.op; }, py::return_value_policy::reference_internal)
         .def_property_readonly("hmatrix", [](DA &s) { return &s.hmat; }, py::return_value_policy::reference_internal)
-        .def_property_readonly("block_diagonal_hmatrix", [](DA &) { return py::none(); });
+        .def_property_readonly("block_diagonal_hmatrix", [](DA &s) -> PyHMatrix<T> * { return s.bdiag.h ? &s.bdiag : nullptr; }, py::return_value_policy::reference_internal);
 }
 
 PYBIND11_MODULE(Htool, m) {

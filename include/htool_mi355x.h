@@ -118,6 +118,13 @@ void htool_build_params_default(htool_build_params *p);
 int htool_hmatrix_build(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
                         const htool_build_params *params, int target_partition_number, int partition_number_for_symmetry,
                         htool_hmatrix **out);
+/* Same, restricted to the columns of one partition of the source tree (source_partition_number >= 0): the
+ * (partition p x partition q) sub-operator behind DefaultLocalApproximationBuilder and
+ * block_diagonal_hmatrix (distributed_operator/utility.hpp:31,34-41).  On a side restricted to a partition the
+ * host-pointer products work on that partition's slice in cluster order. */
+int htool_hmatrix_build_local(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
+                              const htool_build_params *params, int target_partition_number, int source_partition_number,
+                              htool_hmatrix **out);
 void htool_hmatrix_destroy(htool_hmatrix *h);
 int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out); /* __deepcopy__, hmatrix.hpp:48 */
 int htool_hmatrix_is_complex(const htool_hmatrix *h);
@@ -134,7 +141,7 @@ int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, 
 /* device-pointer variants for GPU-resident loops (Krylov, distributed bench): y = H x with
  * x (n_cols) and y (rows of this H-matrix) device buffers.  numbering: 0 = user in and out,
  * 1 = cluster in and out (x is the whole permuted source vector, y the local row slice),
- * 2 = user in, cluster (local row slice) out.  stream = hipStream_t. */
+ * 2 = user in, cluster (local row slice) out, 3 = cluster in, user out.  stream = hipStream_t. */
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream);
 /* Y = H X on device buffers: mu right-hand sides, column c of X at X_dev + c*ldx elements (same for Y).
  * All columns are multiplied in sweeps of up to 8 right-hand sides per pass over the panels. */

@@ -74,6 +74,21 @@ def main(mode):
                 # every rank returns the same replicated result
                 ysum = comm.allreduce(y, op=mpi4py.MPI.SUM)
                 assert np.allclose(ysum, world * y, rtol=1e-13, atol=0)
+        # block-diagonal part of the default approximation (distributed_operator/utility.hpp:31)
+        gen = NumpyGenerator(T, T)
+        holder = Htool.DefaultApproximationBuilder(gen, tcl, tcl, Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N"), comm)
+        bd = holder.block_diagonal_hmatrix
+        assert bd.shape == (local.get_size(), local.get_size())
+        permt = np.asarray(tcl.get_permutation())
+        idx = permt[local.get_offset():local.get_offset() + local.get_size()]
+        Aloc = O.kernel_block(O.K_INV_DELTA, T[:, idx], T[:, idx], 0.1)
+        xs = np.random.RandomState(5).rand(local.get_size())
+        xin = xs
+        if world == 1:  # one rank: the block-diagonal part IS the operator (user numbering on both sides)
+            xin = np.zeros(400); xin[idx] = xs
+            assert np.linalg.norm((bd * xin)[idx] - Aloc @ xs) <= 1e-6 * np.linalg.norm(Aloc @ xs)
+        else:
+            assert np.linalg.norm(bd * xin - Aloc @ xs) <= 1e-6 * np.linalg.norm(Aloc @ xs)
         # Krylov solve through the reference's solver surface (example/use_ddm_solver.py:49-69; our own GMRES,
         # no preconditioner): square symmetric operator on the target cloud, rows split over the ranks
         gen = Htool.NativeGenerator("inv_delta", T, T, 0.1)

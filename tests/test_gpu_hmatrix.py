@@ -293,3 +293,41 @@ def test_edge_shapes(built, oracle, n_t, n_s, dim, children, leaf, eta):
             assert np.array_equal(Y[:, c], H * np.ascontiguousarray(X[:, c]))
         D = H.to_dense_in_user_numbering()
         assert np.linalg.norm(D @ x - y) <= 1e-10 * np.linalg.norm(y) + 1e-300
+
+
+def test_local_blocks_partition_by_partition(built, oracle):
+    """Sub-operators restricted to (target partition p) x (source partition q) -- what block_diagonal_hmatrix and
+    DefaultLocalApproximationBuilder are made of (src/htool/distributed_operator/utility.hpp:31,34-41): summing the
+    P x P local products reproduces the full product; each equals the exact dense sub-block to epsilon."""
+    import Htool
+
+    O = oracle
+    n, P, eps = 3000, 3, 1e-5
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(20)
+    cl = b.create_cluster_tree(pts, 2, size_of_partition=P)
+    perm = np.asarray(cl.get_permutation())
+    gen = Htool.NativeGenerator("laplace", pts, pts)
+    builder = Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N")
+    x = np.random.rand(n)
+    xp = x[perm]
+    yp = np.zeros(n)
+    for p in range(P):
+        tp = cl.get_cluster_on_partition(p)
+        for q in range(P):
+            sq = cl.get_cluster_on_partition(q)
+            H = builder.build_local(gen, cl, cl, p, q)
+            assert H.shape == (tp.get_size(), sq.get_size())
+            xs = xp[sq.get_offset():sq.get_offset() + sq.get_size()]
+            ys = H * xs  # local slices in cluster order on both sides
+            A = O.kernel_block(O.K_LAPLACE, pts[:, perm[tp.get_offset():tp.get_offset() + tp.get_size()]], pts[:, perm[sq.get_offset():sq.get_offset() + sq.get_size()]])
+            assert np.linalg.norm(ys - A @ xs) <= eps * np.linalg.norm(A @ xs)
+            D = H.to_dense()
+            assert np.linalg.norm(D - A) <= 10 * eps * np.linalg.norm(A)
+            yp[tp.get_offset():tp.get_offset() + tp.get_size()] += ys
+    y = np.zeros(n)
+    y[perm] = yp
+    ye = O.dense_matvec(O.K_LAPLACE, pts, pts, x)
+    assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < eps
