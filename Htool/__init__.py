@@ -8,3 +8,30 @@ from htool_python_amd.Htool import *  # noqa: F401,F403
 from htool_python_amd.Htool import __doc__ as _core_doc  # noqa: F401
 from htool_python_amd.plotting import plot  # noqa: F401
 from htool_python_amd.solver import DDMSolverBuilder, Solver  # noqa: F401,E402
+
+# distributed-operator surface: the user-extensible pieces live in Python (htool_python_amd/distributed.py) and wrap
+# the C-ABI-backed default operator; both coefficient types share the implementation
+from htool_python_amd.distributed import (  # noqa: F401,E402
+    CustomApproximationBuilder,
+    DefaultApproximationBuilder,
+    DefaultLocalApproximationBuilder,
+    DistributedOperator,
+    IGlobalToLocalOperator,
+    ILocalToLocalOperator,
+    IRestrictedGlobalToLocalOperator,
+    LocalRenumbering,
+    RestrictedGlobalToLocalOperator,
+    VirtualLocalToLocalOperator,
+)
+
+ComplexDefaultApproximationBuilder = DefaultApproximationBuilder
+ComplexDefaultLocalApproximationBuilder = DefaultLocalApproximationBuilder
+ComplexDistributedOperator = DistributedOperator
+ComplexRestrictedGlobalToLocalOperator = RestrictedGlobalToLocalOperator
+ComplexVirtualLocalToLocalOperator = VirtualLocalToLocalOperator
+
+
+def ComplexCustomApproximationBuilder(target_cluster, source_cluster, comm, operator):
+    import numpy as _np
+
+    return CustomApproximationBuilder(target_cluster, source_cluster, comm, operator, _np.complex128)

@@ -237,7 +237,9 @@ int htool_hmatrix_build(const htool_generator *g, const htool_cluster *target_ro
 int htool_hmatrix_build_local(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
                               int target_partition_number, int source_partition_number, htool_hmatrix **out) {
     API_BEGIN
-    *out = build_hmatrix(g, target_root, source_root, params, target_partition_number, source_partition_number);
+    htool_hmatrix *h = build_hmatrix(g, target_root, source_root, params, target_partition_number, source_partition_number);
+    h->H.local_numbering = true;
+    *out = h;
     API_END
 }
 void htool_hmatrix_destroy(htool_hmatrix *h) { delete h; }
@@ -247,7 +249,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     const HMatrix &s = h->H;
     HMatrix &d = c->H;
     d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
-    d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size;
+    d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size; d.local_numbering = s.local_numbering;
     d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.blocks = s.blocks; d.r_elems = s.r_elems;
     d.build_seconds = s.build_seconds; d.n_batches = s.n_batches;
     c->tch = h->tch; c->sch = h->sch;
@@ -335,7 +337,7 @@ static void densify(const HMatrix &H, void *out, int user_numbering) {
     const int ns = H.col_size;
     const size_t nr = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
     const int BS = 64;
-    if (H.s_root != 0) user_numbering = 1; // local columns: the input side is the local slice in cluster order already
+    if (H.s_root != 0 || H.local_numbering) user_numbering = 1; // local block: both sides are slices in cluster order already
     std::vector<char> e((size_t)ns * BS * es, 0), col(nr * BS * es);
     const double one = 1.0, zero = 0.0;
     for (int j0 = 0; j0 < ns; j0 += BS) {
@@ -605,7 +607,10 @@ int htool_distributed_create_default(const htool_generator *g, const htool_clust
     // block-diagonal part (distributed_operator/utility.hpp:31): needs the source tree to carry the same partition
     const ClusterTree *S = CH(source_root)->tree;
     if (single) d->block_diag = d->hmat;
-    else if ((int)S->part_nodes.size() == comm->size) d->block_diag = build_hmatrix(g, target_root, source_root, params, comm->rank, comm->rank);
+    else if ((int)S->part_nodes.size() == comm->size) {
+        d->block_diag = build_hmatrix(g, target_root, source_root, params, comm->rank, comm->rank);
+        d->block_diag->H.local_numbering = true;
+    }
     *out = d.release();
     API_END
 }

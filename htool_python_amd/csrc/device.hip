@@ -792,7 +792,7 @@ void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int 
 // host API convention: a matrix built on the whole target (source) cluster takes/returns user numbering on
 // that side; one built on a partition works on its local slice in cluster order
 static int host_numbering(const HMatrix &H) {
-    const bool in_user = H.s_root == 0, out_user = H.t_root == 0;
+    const bool in_user = H.s_root == 0 && !H.local_numbering, out_user = H.t_root == 0 && !H.local_numbering;
     return in_user ? (out_user ? 0 : 2) : (out_user ? 3 : 1);
 }
 
@@ -804,7 +804,7 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     HIP_OK(hipMemcpyAsync(D->x_tmp, x, (size_t)D->n_source * es, hipMemcpyHostToDevice, D->stream));
     // a matrix built on the whole target cluster answers in user numbering; one built on a partition
     // answers with its local rows in cluster order
-    const bool whole = H.t_root == 0;
+    const bool whole = H.t_root == 0; // (then row_size == n_target)
     device_matvec_device(H, D->x_tmp, D->y_tmp, host_numbering(H), D->stream);
     HIP_OK(hipMemcpyAsync(y, D->y_tmp, (size_t)(whole ? D->n_target : D->row_size) * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));

@@ -100,6 +100,7 @@ struct HMatrix {
     int row_off = 0, row_size = 0;  // rows covered, cluster numbering
     int s_root = 0;                 // source node (root, or a partition for block-diagonal / local operators)
     int col_off = 0, col_size = 0;  // columns covered, cluster numbering
+    bool local_numbering = false;   // built as a local block: host products use cluster order on both sides
     bool is_complex = false;
     BuildParams params;
     int tile_max = 128;

@@ -74,6 +74,48 @@ def main(mode):
                 # every rank returns the same replicated result
                 ysum = comm.allreduce(y, op=mpi4py.MPI.SUM)
                 assert np.allclose(ysum, world * y, rtol=1e-13, atol=0)
+        # user-extensible operators (tests/test_distributed_operator.py rows "ExtraDiagonal" and
+        # "LocalAndExtraDiagonal", fixtures tests/conftest.py:223-293,352-376)
+        from tests.helpers import CustomLocalToLocalOperator, CustomRestrictedGlobalToLocalOperator
+
+        gen = NumpyGenerator(T, S)
+        t_loc, s_loc = tcl.get_cluster_on_partition(rank), scl.get_cluster_on_partition(rank)
+        extra = []
+        if s_loc.get_offset() > 0:
+            extra.append(CustomRestrictedGlobalToLocalOperator(gen, Htool.LocalRenumbering(t_loc), Htool.LocalRenumbering(0, s_loc.get_offset(), scl.get_permutation()), False, False))
+        rest = scl.get_size() - s_loc.get_size() - s_loc.get_offset()
+        if rest > 0:
+            extra.append(CustomRestrictedGlobalToLocalOperator(gen, Htool.LocalRenumbering(t_loc), Htool.LocalRenumbering(s_loc.get_size() + s_loc.get_offset(), rest, scl.get_permutation()), False, False))
+            assert extra[-1].local_target_renumbering.size == t_loc.get_size() and extra[-1].local_source_renumbering.size == rest
+        for flavour in ("ExtraDiagonal", "LocalAndExtraDiagonal"):
+            if flavour == "ExtraDiagonal":
+                holder = Htool.DefaultLocalApproximationBuilder(gen, tcl, scl, Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N"), comm)
+            else:
+                holder = Htool.CustomApproximationBuilder(tcl, scl, comm, CustomLocalToLocalOperator(gen, Htool.LocalRenumbering(t_loc), Htool.LocalRenumbering(s_loc)))
+            for op_extra in extra:
+                holder.distributed_operator.add_global_to_local_operator(op_extra)
+            opx = holder.distributed_operator
+            assert opx.shape == (400, 200)
+            y = opx * g["x200"]
+            assert np.linalg.norm(y - g["y200"]) / np.linalg.norm(g["y200"]) < 1e-6
+            np.random.seed(2)
+            X = np.asfortranarray(np.random.rand(200, 5))
+            Ye = O.dense_matvec(O.K_INV_DELTA, T, S, X, 0.1)
+            assert np.linalg.norm(opx @ X - Ye) / np.linalg.norm(Ye) < 1e-6
+            # sub-product on a slice of the cluster-numbered input (tests/test_distributed_operator.py:105-129)
+            x = g["x200"].copy()
+            o_, s_ = 20, 20
+            x[:o_] = 0
+            x[o_ + s_:] = 0
+            x_perm = np.zeros(200)
+            x_perm[np.asarray(scl.get_permutation())] = x
+            y1 = opx.internal_sub_vector_product_global_to_local(x[o_:o_ + s_], o_)
+            y2 = O.dense_matvec(O.K_INV_DELTA, T, S, x_perm, 0.1)[np.asarray(tcl.get_permutation())]
+            assert np.linalg.norm(y1 - y2[t_loc.get_offset():t_loc.get_offset() + t_loc.get_size()]) / np.linalg.norm(y2) < 11e-6
+        # same sub-product through the default operator
+        holder = Htool.DefaultApproximationBuilder(gen, tcl, scl, Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N"), comm)
+        y1 = holder.distributed_operator.internal_sub_vector_product_global_to_local(x[o_:o_ + s_], o_)
+        assert np.linalg.norm(y1 - y2[t_loc.get_offset():t_loc.get_offset() + t_loc.get_size()]) / np.linalg.norm(y2) < 11e-6
         # block-diagonal part of the default approximation (distributed_operator/utility.hpp:31)
         gen = NumpyGenerator(T, T)
         holder = Htool.DefaultApproximationBuilder(gen, tcl, tcl, Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N"), comm)

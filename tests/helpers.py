@@ -108,3 +108,39 @@ def cpu_leaf_loop(hmatrix, x_user, is_complex=False):
     y = np.zeros(len(pt), dtype=dt)
     y[pt] = yp
     return y
+
+
+class CustomRestrictedGlobalToLocalOperator(Htool.RestrictedGlobalToLocalOperator):
+    """Dense extra-diagonal block as a user operator (example/advanced/define_custom_local_operator.py:6-50)."""
+
+    def __init__(self, generator, target_local_renumbering, source_local_renumbering, target_use_permutation_to_mvprod=False, source_use_permutation_to_mvprod=False):
+        super().__init__(target_local_renumbering, source_local_renumbering, target_use_permutation_to_mvprod, source_use_permutation_to_mvprod)
+        t, s = target_local_renumbering, source_local_renumbering
+        self.data = np.zeros((t.size, s.size), order="F")
+        generator.build_submatrix(t.permutation[t.offset:t.offset + t.size], s.permutation[s.offset:s.offset + s.size], self.data)
+
+    def add_vector_product(self, trans, alpha, input, beta, output):
+        output *= beta
+        output += alpha * (self.data if trans == "N" else self.data.T).dot(input)
+
+    def add_matrix_product_row_major(self, trans, alpha, input, beta, output):
+        output *= beta
+        output += alpha * (self.data if trans == "N" else self.data.T) @ input
+
+
+class CustomLocalToLocalOperator(Htool.VirtualLocalToLocalOperator):
+    """Dense diagonal block as a user operator (example/advanced/define_custom_local_operator.py:53-100)."""
+
+    def __init__(self, generator, target_local_renumbering, source_local_renumbering):
+        super().__init__(target_local_renumbering, source_local_renumbering)
+        t, s = target_local_renumbering, source_local_renumbering
+        self.data = np.zeros((t.size, s.size), order="F")
+        generator.build_submatrix(t.permutation[t.offset:t.offset + t.size], s.permutation[s.offset:s.offset + s.size], self.data)
+
+    def local_add_vector_product(self, trans, alpha, input, beta, output):
+        output *= beta
+        output += alpha * (self.data if trans == "N" else self.data.T).dot(input)
+
+    def local_add_matrix_product_row_major(self, trans, alpha, input, beta, output):
+        output *= beta
+        output += alpha * (self.data if trans == "N" else self.data.T) @ input
