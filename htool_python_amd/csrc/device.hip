@@ -119,11 +119,14 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
 #pragma unroll
                     for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
                 }
-            } else {
-                for (int u = 0; u < nc; u++) {
-                    double2 v = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+            } else { // tail group: same unrolled batch, loads predicated (coefficients beyond nc are zero)
+                double2 v[CH];
 #pragma unroll
-                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v, Ops::bcast(coef[r], u));
+                for (int u = 0; u < CH; u++) v[u] = (active && u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
                 }
             }
         }
@@ -197,11 +200,14 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
 #pragma unroll
                         for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], cc + u));
                     }
-                } else {
-                    for (int u = 0; cc + u < nc; u++) {
-                        double2 v = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+                } else { // tail group: same unrolled batch, loads predicated (coefficients beyond nc are zero)
+                    double2 v[CH];
 #pragma unroll
-                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v, Ops::bcast(coef[r], cc + u));
+                    for (int u = 0; u < CH; u++) v[u] = (active && cc + u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < CH; u++) {
+#pragma unroll
+                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], (cc + u) & 63));
                     }
                 }
             }
