@@ -41,7 +41,6 @@ struct RealOps {
     typedef double T;
     static constexpr int RPL = 2; // rows per lane
     static __device__ __forceinline__ T zero() { return 0.0; }
-    static __device__ __forceinline__ T one() { return 1.0; }
     static __device__ __forceinline__ T bcast(T v, int src) { return bcast_f64(v, src); }
     static __device__ __forceinline__ void fma(double2 &acc, const double2 v, const T w) {
         acc.x = ::fma(v.x, w, acc.x);
@@ -53,7 +52,6 @@ struct CplxOps {
     typedef double2 T;
     static constexpr int RPL = 1;
     static __device__ __forceinline__ T zero() { return make_double2(0.0, 0.0); }
-    static __device__ __forceinline__ T one() { return make_double2(1.0, 0.0); }
     static __device__ __forceinline__ T bcast(T v, int src) { return make_double2(bcast_f64(v.x, src), bcast_f64(v.y, src)); }
     static __device__ __forceinline__ void fma(double2 &acc, const double2 v, const T w) {
         acc.x = ::fma(v.x, w.x, ::fma(-v.y, w.y, acc.x));
@@ -244,9 +242,6 @@ __global__ void reduce_y_kernel(const T *__restrict__ ypart, long long stride, i
         y[r * y_stride + dst] = acc;
     }
 }
-
-template <typename T>
-__global__ void set_one_kernel(T *W, long long idx, T one) { W[idx] = one; }
 
 // ------------------------------------------------------------------------------------------------
 // native generators evaluated on device (cluster-ordered SoA coordinates: x[0:n) y[0:n) z[0:n))
