@@ -46,10 +46,11 @@ def main():
     solver.set_hpddm_args("-hpddm_krylov_method gmres -hpddm_tol 1e-8 -hpddm_max_it 500 -hpddm_gmres_restart 100")
     solver.facto_one_level()
     solver.solve(x, b)
+    distributed_information = hmatrix.get_distributed_information(comm)  # collective: every rank calls it
     if comm.rank == 0:
         print("solution error", np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref))
         print(solver.get_information())
-        print(hmatrix.get_distributed_information(comm))
+        print(distributed_information)
     assert np.linalg.norm(A @ x - b) / np.linalg.norm(b) < 1e-6
     comm.Barrier()
 

@@ -62,7 +62,9 @@ def main(mode):
                 holder = Htool.DefaultApproximationBuilder(gen, tcl, scl, Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N"), comm)
                 op, local_h = holder.distributed_operator, holder.hmatrix
                 assert op.shape == (comm.allreduce(local_h.shape[0], op=mpi4py.MPI.SUM), local_h.shape[1]) == (400, 200)
-                print(local_h.get_distributed_information(comm) if rank == 0 else "", end="")
+                dinfo = local_h.get_distributed_information(comm)
+                nblocks = comm.allreduce(len(local_h.leaves()), op=mpi4py.MPI.SUM)
+                assert int(dinfo["Number_of_dense_blocks"]) + int(dinfo["Number_of_low_rank_blocks"]) == nblocks
                 y = op * g["x200"]
                 assert np.linalg.norm(y - g["y200"]) / np.linalg.norm(g["y200"]) < eps
                 for mu in (5, 1):

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _launch(world, mode, timeout=600):
+def _launch(world, mode, timeout=240):
     env = dict(os.environ)
     env["OMP_NUM_THREADS"] = "2"
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"

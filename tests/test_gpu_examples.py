@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(cmd, timeout=600):
+def _run(cmd, timeout=180):
     env = dict(os.environ, MPLBACKEND="Agg", OMP_NUM_THREADS="4")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-2000:]
