@@ -42,6 +42,7 @@ struct RealOps {
     static constexpr int RPL = 2; // rows per lane
     static __device__ __forceinline__ T zero() { return 0.0; }
     static __device__ __forceinline__ T bcast(T v, int src) { return bcast_f64(v, src); }
+    static __device__ __forceinline__ T shfl(T v, int src) { return __shfl(v, src); } // per-lane source
     static __device__ __forceinline__ void fma(double2 &acc, const double2 v, const T w) {
         acc.x = ::fma(v.x, w, acc.x);
         acc.y = ::fma(v.y, w, acc.y);
@@ -53,6 +54,7 @@ struct CplxOps {
     static constexpr int RPL = 1;
     static __device__ __forceinline__ T zero() { return make_double2(0.0, 0.0); }
     static __device__ __forceinline__ T bcast(T v, int src) { return make_double2(bcast_f64(v.x, src), bcast_f64(v.y, src)); }
+    static __device__ __forceinline__ T shfl(T v, int src) { return make_double2(__shfl(v.x, src), __shfl(v.y, src)); }
     static __device__ __forceinline__ void fma(double2 &acc, const double2 v, const T w) {
         acc.x = ::fma(v.x, w.x, ::fma(-v.y, w.y, acc.x));
         acc.y = ::fma(v.x, w.y, ::fma(v.y, w.x, acc.y));
@@ -79,7 +81,10 @@ __device__ __forceinline__ void store_rows(typename Ops::T *out, const GTile &tl
 // ------------------------------------------------------------------------------------------------
 // phase B: few rows (<= 64*RPL), many columns; the four waves split the columns, LDS combine.
 // ------------------------------------------------------------------------------------------------
-template <typename Ops, int CH, int NR>
+// F = columns handled side by side by one wave instruction: 1 for tiles that fill the 64 lanes, 2 / 4 for
+// short tiles (small cluster leaves), where lane group g = lane / (64/F) takes column u*F + g.  Tiles are sorted
+// into the three classes at assembly time; every class is its own launch (registers stay those of its code path).
+template <typename Ops, int CH, int NR, int F>
 __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
                                                       const typename Ops::T *__restrict__ W, typename Ops::T *__restrict__ out,
                                                       long long w_stride, long long out_stride) {
@@ -87,48 +92,92 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
     const GTile tl = tiles[blockIdx.x];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row0 = lane * Ops::RPL;
-    const bool active = row0 < tl.nrows;
     double2 acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = make_double2(0.0, 0.0);
-    for (int s = 0; s < tl.nseg; s++) {
-        const GSeg sg = segs[tl.seg_begin + s];
-        const T *base = (const T *)sg.panel + row0;
-        const long long ld = sg.ld_last;
-        const int ncols = sg.ncols;
-        for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
-            const int nc = min(CH, ncols - c0);
-            T coef[NR];
+    if (F == 1) {
+        const int row0 = lane * Ops::RPL;
+        const bool active = row0 < tl.nrows;
+        for (int s = 0; s < tl.nseg; s++) {
+            const GSeg sg = segs[tl.seg_begin + s];
+            const T *base = (const T *)sg.panel + row0;
+            const long long ld = sg.ld_last;
+            const int ncols = sg.ncols;
+            for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
+                const int nc = min(CH, ncols - c0);
+                T coef[NR];
 #pragma unroll
-            for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
-            if (lane < nc) {
-                const long long ci = sg.cidx[c0 + lane];
+                for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
+                if (lane < nc) {
+                    const long long ci = sg.cidx[c0 + lane];
 #pragma unroll
-                for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
-            }
-            const T *p = base + (long long)c0 * ld;
-            if (nc == CH) {
-                double2 v[CH];
-#pragma unroll
-                for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
-#pragma unroll
-                for (int u = 0; u < CH; u++) {
-#pragma unroll
-                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
+                    for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
                 }
-            } else { // tail group: same unrolled batch, loads predicated (coefficients beyond nc are zero)
-                double2 v[CH];
+                const T *p = base + (long long)c0 * ld;
+                if (nc == CH) {
+                    double2 v[CH];
 #pragma unroll
-                for (int u = 0; u < CH; u++) v[u] = (active && u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+                    for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
-                for (int u = 0; u < CH; u++) {
+                    for (int u = 0; u < CH; u++) {
 #pragma unroll
-                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
+                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
+                    }
+                } else { // tail group: same unrolled batch, loads predicated (coefficients beyond nc are zero)
+                    double2 v[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; u++) v[u] = (active && u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int u = 0; u < CH; u++) {
+#pragma unroll
+                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], u));
+                    }
                 }
             }
         }
+    } else {
+        constexpr int LPG = 64 / F;             // lanes per column group
+        constexpr int GC = CH * F;              // columns per batch of CH loads (<= 64)
+        const int g = lane / LPG, li = lane - g * LPG;
+        const int row0 = li * Ops::RPL;
+        const bool active = row0 < tl.nrows;
+        for (int s = 0; s < tl.nseg; s++) {
+            const GSeg sg = segs[tl.seg_begin + s];
+            const long long ld = sg.ld_last;
+            const T *base = (const T *)sg.panel + row0 + (long long)g * ld;
+            const int ncols = sg.ncols;
+            for (int c0 = wave * GC; c0 < ncols; c0 += 4 * GC) {
+                const int nc = min(GC, ncols - c0);
+                T coef[NR];
+#pragma unroll
+                for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
+                if (lane < nc) {
+                    const long long ci = sg.cidx[c0 + lane];
+#pragma unroll
+                    for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
+                }
+                const T *p = base + (long long)c0 * ld;
+                double2 v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) v[u] = (active && u * F + g < nc) ? ldnt16(p + (long long)(u * F) * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::shfl(coef[r], u * F + g));
+                }
+            }
+        }
+        // add the F column groups (butterfly: every lane ends with the total of its row pair)
+#pragma unroll
+        for (int off = LPG; off < 64; off <<= 1) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                acc[r].x += __shfl_xor(acc[r].x, off);
+                acc[r].y += __shfl_xor(acc[r].y, off);
+            }
+        }
     }
+    const int row0 = lane * Ops::RPL;
     __shared__ double2 red[NR][4][64];
 #pragma unroll
     for (int r = 0; r < NR; r++) red[r][wave][lane] = acc[r];
@@ -161,6 +210,17 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
     const int row0 = lane * Ops::RPL;
     const int nq = (tl.nrows + TM - 1) / TM;
     const int ncols = sg.ncols;
+    // all row chunks of a tile share the columns, hence the coefficients: with at most 64 columns (always the
+    // case in phase A, where the columns are one source tile) they are fetched once per wave, not per chunk
+    const bool single = ncols <= 64;
+    T coef1[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) coef1[r] = Ops::zero();
+    if (single && lane < ncols) {
+        const long long ci = sg.cidx[lane];
+#pragma unroll
+        for (int r = 0; r < NR; r++) coef1[r] = W[r * w_stride + ci];
+    }
     for (int q = wave; q < nq; q += 4) {
         const int rows_here = min(TM, tl.nrows - q * TM);
         const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
@@ -173,8 +233,8 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
             const int nc = min(64, ncols - c0);
             T coef[NR];
 #pragma unroll
-            for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
-            if (lane < nc) {
+            for (int r = 0; r < NR; r++) coef[r] = coef1[r];
+            if (!single && lane < nc) {
                 const long long ci = sg.cidx[c0 + lane];
 #pragma unroll
                 for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
@@ -665,6 +725,19 @@ struct DeviceBuilder {
             sort_heavy(tBs, wBs, nullptr);
         }
         sort_heavy(tB, wB, &tBc);
+        // classes of the wide kernel (columns per wave instruction F = 1, 2, 4), heavy-first inside each class
+        auto tile_class = [&](const GTile &t) { int lanes = (t.nrows + vec_rows - 1) / vec_rows; return lanes <= 16 ? 2 : (lanes <= 32 ? 1 : 0); };
+        auto by_class = [&](std::vector<GTile> &t, std::vector<GTile> *twin, int *cnt) {
+            std::vector<GTile> o, o2;
+            for (int c = 0; c < 3; c++) {
+                cnt[c] = 0;
+                for (size_t i = 0; i < t.size(); i++) if (tile_class(t[i]) == c) { o.push_back(t[i]); if (twin) o2.push_back((*twin)[i]); cnt[c]++; }
+            }
+            t.swap(o);
+            if (twin) twin->swap(o2);
+        };
+        by_class(tB, &tBc, D->cntB);
+        by_class(tBs, nullptr, D->cntBs);
         sort_heavy(tA, wA, nullptr);
         sort_heavy(tA2, wA2, nullptr);
         D->segs = upload(segs, &D->table_bytes);
@@ -711,13 +784,21 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     HIP_OK(hipEventRecord(ev[2], st));
     if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W, ws, ws, ws);
     HIP_OK(hipEventRecord(ev[3], st));
+    auto launch_wide = [&](const GTile *tiles, const int *cnt, T *out, long long out_stride) {
+        const GTile *t = tiles;
+        if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 1>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
+        t += cnt[0];
+        if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 2>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
+        t += cnt[1];
+        if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 4>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
+    };
     if (D->splitB > 1 && D->nB_split) {
         const long long ps = (long long)D->splitB * D->ypart_stride;
-        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, (T *)D->ypart, ws, ps);
+        launch_wide(D->tilesB_split, D->cntBs, (T *)D->ypart, ps);
         hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
                            out_user ? D->perm_t + D->row_off : (const int *)nullptr, (T *)y_dev, y_stride, NR);
     } else if (D->nB) {
-        hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR>), dim3(D->nB), dim3(256), 0, st, out_user ? D->tilesB_user : D->tilesB_cluster, D->segs, (const T *)W, (T *)y_dev, ws, y_stride);
+        launch_wide(out_user ? D->tilesB_user : D->tilesB_cluster, D->cntB, (T *)y_dev, y_stride);
     }
     HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());

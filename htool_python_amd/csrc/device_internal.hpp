@@ -59,6 +59,7 @@ struct DeviceHMatrix {
     // small operators: every row tile is cut in splitB column slices (more, smaller workgroups); the slices
     // write partial sums to ypart[slice][row] and reduce_y_kernel adds them in slice order
     int splitB = 1, nB_split = 0;
+    int cntB[3] = {0, 0, 0}, cntBs[3] = {0, 0, 0}; // tiles per class of the wide kernel (F = 1, 2, 4 columns per wave instruction)
     GTile *tilesB_split = nullptr;
     void *ypart = nullptr;
     long long ypart_stride = 0;
