@@ -191,9 +191,13 @@ def main():
         x_full = torch.zeros(n, dtype=dtype, device="cuda")
         y = torch.zeros(n_rows, dtype=dtype, device="cuda")
         equal = len(set(sizes)) == 1
-        parts = None if equal else list(torch.split(x_full, sizes))
-
         host_parts = [torch.empty(sz, dtype=dtype) for sz in sizes]
+        # unequal partitions: gather equal-size padded slices (RCCL all-gather wants equal counts), then compact
+        if not equal:
+            pad = max(sizes)
+            x_pad = torch.zeros(pad, dtype=dtype, device="cuda")
+            gathered = torch.zeros(world, pad, dtype=dtype, device="cuda")
+            offs = [sum(sizes[:p]) for p in range(world)]
 
         def step():
             # exchange: every GPU contributes its slice of x (cluster numbering), RCCL over xGMI
@@ -203,7 +207,10 @@ def main():
             elif equal:
                 dist.all_gather_into_tensor(x_full, x_local)
             else:
-                dist.all_gather(parts, x_local)
+                x_pad[: x_local.numel()].copy_(x_local)
+                dist.all_gather_into_tensor(gathered, x_pad)
+                for p_ in range(world):
+                    x_full[offs[p_]: offs[p_] + sizes[p_]].copy_(gathered[p_, : sizes[p_]])
             H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
 
     gmres_info = None

@@ -62,8 +62,16 @@ class DeviceOperator:
             if dist.get_backend(self.group) == "nccl":
                 if len(set(sizes)) == 1:
                     dist.all_gather_into_tensor(self._full, x_local.contiguous(), group=self.group)
-                else:
-                    dist.all_gather(list(torch.split(self._full, sizes)), x_local.contiguous(), group=self.group)
+                else:  # equal-size padded slices, then compact
+                    pad = max(sizes)
+                    xp = torch.zeros(pad, dtype=x_local.dtype, device=x_local.device)
+                    xp[: x_local.numel()].copy_(x_local)
+                    g = torch.empty(self.world, pad, dtype=x_local.dtype, device=x_local.device)
+                    dist.all_gather_into_tensor(g, xp, group=self.group)
+                    o = 0
+                    for p, sz in enumerate(sizes):
+                        self._full[o:o + sz].copy_(g[p, :sz])
+                        o += sz
             else:  # host-staged exchange (gloo): several ranks may share one GPU
                 parts = [torch.empty(s, dtype=x_local.dtype) for s in sizes]
                 dist.all_gather(parts, x_local.cpu(), group=self.group)
