@@ -188,29 +188,15 @@ def main():
         if is_complex:
             x_local = torch.complex(x_local, torch.rand(local.get_size(), dtype=torch.float64, generator=gen_t))
         x_local = x_local.cuda()
-        x_full = torch.zeros(n, dtype=dtype, device="cuda")
         y = torch.zeros(n_rows, dtype=dtype, device="cuda")
-        equal = len(set(sizes)) == 1
-        host_parts = [torch.empty(sz, dtype=dtype) for sz in sizes]
-        # unequal partitions: gather equal-size padded slices (RCCL all-gather wants equal counts), then compact
-        if not equal:
-            pad = max(sizes)
-            x_pad = torch.zeros(pad, dtype=dtype, device="cuda")
-            gathered = torch.zeros(world, pad, dtype=dtype, device="cuda")
-            offs = [sum(sizes[:p]) for p in range(world)]
+        from htool_python_amd.comm import SliceGatherer
+
+        gather = SliceGatherer(sizes, dtype, "cuda")
 
         def step():
-            # exchange: every GPU contributes its slice of x (cluster numbering), RCCL over xGMI
-            if args.backend == "gloo":
-                dist.all_gather(host_parts, x_local.cpu())
-                x_full.copy_(torch.cat(host_parts))
-            elif equal:
-                dist.all_gather_into_tensor(x_full, x_local)
-            else:
-                x_pad[: x_local.numel()].copy_(x_local)
-                dist.all_gather_into_tensor(gathered, x_pad)
-                for p_ in range(world):
-                    x_full[offs[p_]: offs[p_] + sizes[p_]].copy_(gathered[p_, : sizes[p_]])
+            # exchange: every GPU contributes its slice of x (cluster numbering) -- RCCL all-gather over xGMI --
+            # then multiplies its rows
+            x_full = gather(x_local)
             H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
 
     gmres_info = None
@@ -251,21 +237,11 @@ def main():
 
     tot_bytes = float(ab["total"])
     if args.check and world > 1:
-        # distributed result vs exact rows: gather y slices and x slices on every rank
-        ys = [torch.empty(sz, dtype=dtype) for sz in sizes]
-        xs = [torch.empty(sz, dtype=dtype) for sz in sizes]
-        if args.backend == "gloo":
-            dist.all_gather(ys, y.cpu())
-            dist.all_gather(xs, x_local.cpu())
-        else:
-            ysd, xsd = [t.cuda() for t in ys], [t.cuda() for t in xs]
-            dist.all_gather(ysd, y)
-            dist.all_gather(xsd, x_local)
-            ys, xs = [t.cpu() for t in ysd], [t.cpu() for t in xsd]
+        # distributed result vs exact rows: gather the y slices and the x slices on every rank
         perm = np.asarray(cluster.get_permutation())
-        y_user, x_user = np.zeros(n, dtype=ys[0].numpy().dtype), np.zeros(n, dtype=ys[0].numpy().dtype)
-        y_user[perm] = torch.cat(ys).numpy()
-        x_user[perm] = torch.cat(xs).numpy()
+        y_user, x_user = np.zeros(n, dtype=np.complex128 if is_complex else np.float64), np.zeros(n, dtype=np.complex128 if is_complex else np.float64)
+        y_user[perm] = SliceGatherer(sizes, dtype, "cuda")(y).cpu().numpy()
+        x_user[perm] = SliceGatherer(sizes, dtype, "cuda")(x_local).cpu().numpy()
     if world > 1:
         t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()

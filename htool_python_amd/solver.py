@@ -46,37 +46,19 @@ class DeviceOperator:
         self.group, self.shift = group, shift
         self.offset, self.size = self.partition[rank]
         self.products = 0
-        self._full = None
+        self._gather = None
 
     def apply(self, x_local):
-        import torch.distributed as dist
-
         y = torch.empty(self.size, dtype=x_local.dtype, device=x_local.device)
         stream = torch.cuda.current_stream().cuda_stream
         if self.world == 1:
             xf = x_local.contiguous()
         else:
-            if self._full is None:
-                self._full = torch.empty(self.n, dtype=x_local.dtype, device=x_local.device)
-            sizes = [s for _, s in self.partition]
-            if dist.get_backend(self.group) == "nccl":
-                if len(set(sizes)) == 1:
-                    dist.all_gather_into_tensor(self._full, x_local.contiguous(), group=self.group)
-                else:  # equal-size padded slices, then compact
-                    pad = max(sizes)
-                    xp = torch.zeros(pad, dtype=x_local.dtype, device=x_local.device)
-                    xp[: x_local.numel()].copy_(x_local)
-                    g = torch.empty(self.world, pad, dtype=x_local.dtype, device=x_local.device)
-                    dist.all_gather_into_tensor(g, xp, group=self.group)
-                    o = 0
-                    for p, sz in enumerate(sizes):
-                        self._full[o:o + sz].copy_(g[p, :sz])
-                        o += sz
-            else:  # host-staged exchange (gloo): several ranks may share one GPU
-                parts = [torch.empty(s, dtype=x_local.dtype) for s in sizes]
-                dist.all_gather(parts, x_local.cpu(), group=self.group)
-                self._full.copy_(torch.cat(parts))
-            xf = self._full
+            if self._gather is None:
+                from .comm import SliceGatherer
+
+                self._gather = SliceGatherer([s for _, s in self.partition], x_local.dtype, x_local.device, self.group)
+            xf = self._gather(x_local)
         self.H.matvec_device(xf.data_ptr(), y.data_ptr(), 1, stream)
         self.products += 1
         if self.shift != 0.0:
@@ -84,15 +66,10 @@ class DeviceOperator:
         return y
 
     def reduce(self, t):
-        import torch.distributed as dist
-
         if self.world > 1:
-            if dist.get_backend(self.group) == "nccl":
-                dist.all_reduce(t, group=self.group)
-            else:
-                h = t.cpu()
-                dist.all_reduce(h, group=self.group)
-                t.copy_(h)
+            from .comm import all_reduce_sum
+
+            all_reduce_sum(t, self.group)
         return t
 
 
@@ -152,19 +129,11 @@ class Solver:
                       "Products": str(self.op.products), "Krylov_method": "gmres", "Preconditioner": "none"}
 
     def _gather(self, xl):
-        import torch.distributed as dist
-
         if self.op.world == 1:
             return xl.cpu().numpy()
-        parts = [torch.empty(s, dtype=xl.dtype) for _, s in self.op.partition]
-        host = xl.cpu()
-        if dist.get_backend(self.op.group) == "nccl":
-            dev = [p.cuda() for p in parts]
-            dist.all_gather(dev, xl.contiguous(), group=self.op.group)
-            parts = [p.cpu() for p in dev]
-        else:
-            dist.all_gather(parts, host, group=self.op.group)
-        return torch.cat(parts).numpy()
+        from .comm import SliceGatherer
+
+        return SliceGatherer([s for _, s in self.op.partition], xl.dtype, xl.device, self.op.group)(xl).cpu().numpy()
 
     def get_information(self):
         return dict(self._info)
