@@ -233,3 +233,40 @@ def test_high_accuracy_exercises_capacity_growth_and_resplit(built, oracle, eps,
     x = np.random.rand(n)
     ye = O.dense_matvec(O.K_LAPLACE, pts, pts, x)
     assert np.linalg.norm(H * x - ye) / np.linalg.norm(ye) < max(10 * eps, 1e-13)
+
+
+@pytest.mark.parametrize("kind,p0,symmetry,uplo", [(0, 0.1, "S", "L"), (0, 0.1, "N", "N"), (1, 0.0, "S", "L"), (1, 0.0, "N", "N")])
+def test_config_c1_use_hmatrix_10k(built, oracle, kind, p0, symmetry, uplo):
+    """BASELINE config C1: example/use_hmatrix.py scaled to 10 000 points (eta=10, eps=1e-3, leaf 50, 'S','L' as in
+    use_hmatrix.py:42 and 'N'), both kernels of SURVEY 8d: full parity -- block structure and ranks equal the CPU
+    restatement's, product equal to the oracle's product and to the exact dense operator."""
+    import Htool
+    from htool_python_amd.workloads import points_in_sphere
+    from tests.helpers import cluster_of
+
+    O = oracle
+    n, eps, eta, leaf = 10_000, 1e-3, 10.0, 50
+    pts = points_in_sphere(n, seed=0)
+    cl = cluster_of(pts, leaf)
+    name = {0: "inv_delta", 1: "laplace"}[kind]
+    H = Htool.HMatrixTreeBuilder(eps, eta, symmetry, uplo).build(Htool.NativeGenerator(name, pts, pts, p0), cl, cl)
+    np.random.seed(0)
+    x = np.random.rand(n)  # use_hmatrix.py:48-49
+    y = H * x
+    y_exact = O.dense_matvec(kind, pts, pts, x, p0)
+    assert np.linalg.norm(y - y_exact) / np.linalg.norm(y_exact) < eps
+    oc = O.Cluster(pts, max_leaf=leaf)
+    OH = O.HMatrix(oc, oc, kind, p0, eps=eps, eta=eta, symmetry=symmetry, uplo=uplo)
+    assert np.linalg.norm(y - OH.matvec(x)) / np.linalg.norm(y_exact) < 1e-5  # ranks may differ by one step on < 1 % of the leaves
+    mine = {tuple(l[:4]): int(l[4]) for l in np.asarray(H.leaves())}
+    theirs = {tuple(l[:4]): int(l[4]) for l in OH.leaves}
+    if symmetry == "N":
+        assert set(mine) == set(theirs)
+    else:  # the oracle stores one triangle, the engine both: the stored triangle must coincide
+        assert set(theirs) <= set(mine) and all((k[2], k[3], k[0], k[1]) in mine for k in theirs)
+    diff = np.array([mine[k] - theirs[k] for k in theirs])
+    assert np.mean(diff != 0) < 0.01 and np.abs(diff).max() <= 1
+    X = np.random.rand(n, 2)
+    Y = H @ X
+    Ye = O.dense_matvec(kind, pts, pts, X, p0)
+    assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < eps
