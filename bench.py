@@ -38,6 +38,34 @@ def pmc_traffic(args, n):
         return json.load(f).get("tile_gemv_wide_hbm_bytes_per_launch")
 
 
+def cpu_build_sample(n_sample=150_000):
+    """Build seconds, CPU oracle (OpenMP) vs this engine, on the same bounded instance: the first n_sample points of
+    the seeded cloud (a uniform sample of the ball), same kernel / eps / eta / leaf size as the bench workload."""
+    import numpy as np
+
+    import Htool
+    from htool_python_amd.workloads import points_in_sphere
+    from oracle import oracle as O
+
+    a = cpu_build_sample.args
+    if a.kernel != "laplace":
+        return None
+    pts = np.ascontiguousarray(points_in_sphere(a.n, seed=0)[:, :n_sample])
+    t0 = time.perf_counter()
+    oc = O.Cluster(pts, max_leaf=a.leaf)
+    OH = O.HMatrix(oc, oc, O.K_LAPLACE, eps=a.eps, eta=a.eta)
+    t_cpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cb = Htool.ClusterTreeBuilder()
+    cb.set_maximal_leaf_size(a.leaf)
+    cl = cb.create_cluster_tree(pts, 2)
+    Hs = Htool.HMatrixTreeBuilder(a.eps, a.eta, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts), cl, cl)
+    t_gpu = time.perf_counter() - t0
+    same = len(OH.leaves) == len(Hs.leaves())
+    return {"points": n_sample, "cpu_oracle_s": t_cpu, "gpu_s": t_gpu, "threads": O.num_threads(), "same_leaf_count": bool(same),
+            "note": "cluster tree + block tree + ACA + dense fill; oracle/hmat_oracle.cpp with OpenMP vs this engine (host trees, device ACA)"}
+
+
 def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
     """CPU leaf loop (oracle, OpenMP) on a bounded random sample of this operator's own leaves."""
     import numpy as np
@@ -75,7 +103,9 @@ def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
         t_all.append(time.perf_counter() - t0)
         reps += 1
     t_med = sorted(t_all)[len(t_all) // 2]
+    build = cpu_build_sample()
     return {
+        "build_sample": build,
         "value": tot / t_med / 1e9,
         "unit": "GB/s",
         "cores": O.num_threads(),
@@ -107,6 +137,7 @@ def main():
     ap.add_argument("--shift", type=float, default=0.0, help="diagonal shift of the --gmres system (0: N/50, keeps the system well posed)")
     ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
     args = ap.parse_args()
+    cpu_build_sample.args = args
 
     import numpy as np
     import torch
