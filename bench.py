@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the measured path; gloo stages the exchange through the host so that the "
                          "multi-rank logic can be rehearsed with several ranks on ONE GPU (not a benchmark)")
+    ap.add_argument("--recompress", action="store_true", help="run Htool.recompression (device SVD recompression of the low-rank leaves) after the build")
     ap.add_argument("--rhs", type=int, default=1, help="right-hand sides per step (H @ X, one sweep of the panels per 8 columns); 1 = the headline matvec")
     ap.add_argument("--gmres", type=int, default=0, help="BASELINE config 5: instead of bare products, a step is ONE GMRES iteration (restart = this value) "
                                                         "on (shift I + H) with device-resident Krylov vectors")
@@ -189,6 +190,12 @@ def main():
     H = builder.build(gen, cluster, cluster, rank if world > 1 else -1)
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    t_recompress = None
+    if args.recompress:
+        t0 = time.time()
+        Htool.recompression(H)
+        torch.cuda.synchronize()
+        t_recompress = time.time() - t0
     leaves = H.leaves()
     n_rows = H.shape[0]
     ab = algorithmic_bytes(leaves, n, n_rows, elem)
@@ -298,11 +305,12 @@ def main():
         "backend": ("rccl" if args.backend == "nccl" else "gloo-host-staged (rehearsal, not a benchmark)") if world > 1 else None,
         "config": {
             "workload": f"{n}-point 3D {args.kernel} H-matrix matvec (BASELINE configs[3] operator{' on one GPU' if world == 1 else ', row-cluster split'}), "
-                        f"eta={args.eta:g}, eps={args.eps:g}, leaf={args.leaf}, ACA on device, points seed 0 unit ball",
+                        f"eta={args.eta:g}, eps={args.eps:g}, leaf={args.leaf}, ACA on device{' + SVD recompression' if args.recompress else ''}, points seed 0 unit ball",
             "n_points": n, "eps": args.eps, "eta": args.eta, "leaf": args.leaf, "kernel": args.kernel,
             "parallelism": f"rows{world}" if world > 1 else "single",
         },
         "build_s": t_build,
+        "recompression_s": t_recompress,
         "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,
         "rhs_per_step": args.rhs,

@@ -257,6 +257,12 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     *out = c.release();
     API_END
 }
+int htool_hmatrix_recompress(htool_hmatrix *h, double epsilon, int64_t *n_reduced) {
+    API_BEGIN
+    int64_t c = device_recompress(h->H, epsilon);
+    if (n_reduced) *n_reduced = c;
+    API_END
+}
 int htool_hmatrix_is_complex(const htool_hmatrix *h) { return h->H.is_complex ? 1 : 0; }
 int htool_hmatrix_nb_rows(const htool_hmatrix *h) { return h->H.row_size; }
 int htool_hmatrix_nb_cols(const htool_hmatrix *h) { return h->H.col_size; }

@@ -362,7 +362,9 @@ struct PackArgs {
     DevGen gen;
 };
 
-template <typename T>
+// REVERSE = false: arena -> tile panels (pack).  REVERSE = true: tile panels -> arena (bulk unpack, used by the
+// recompression pass).
+template <typename T, bool REVERSE>
 __global__ __launch_bounds__(256) void pack_u_kernel(PackArgs a) {
     const int it = blockIdx.x;
     const DevBlock b = a.blocks[a.item_block[it]];
@@ -372,10 +374,14 @@ __global__ __launch_bounds__(256) void pack_u_kernel(PackArgs a) {
     const int ncols = b.rank >= 0 ? b.rank : b.n;
     T *dst = (T *)a.panel + a.tile_pbase[r] + (long long)b.ucol * ld;
     int *cidx = a.index + a.tile_ibase[r] + b.ucol;
-    const T *src = (const T *)a.arena + b.tmp_u + (toff - b.t_off);
+    T *src = (T *)const_cast<void *>(a.arena) + b.tmp_u + (toff - b.t_off);
     const int total = ncols * ld;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int k = e / ld, i = e - k * ld;
+        if (REVERSE) {
+            if (i < ts) src[(long long)k * b.m + i] = dst[(long long)k * ld + i];
+            continue;
+        }
         T v;
         if (i >= ts) v = T{};
         else if (b.rank < 0 && a.eval_dense) gen_eval(a.gen, toff + i, b.s_off + k, v);
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256) void pack_u_kernel(PackArgs a) {
     }
 }
 
-template <typename T>
+template <typename T, bool REVERSE>
 __global__ __launch_bounds__(256) void pack_v_kernel(PackArgs a) {
     const int it = blockIdx.x;
     const DevBlock b = a.blocks[a.item_block[it]];
@@ -398,14 +404,16 @@ __global__ __launch_bounds__(256) void pack_v_kernel(PackArgs a) {
     const int ld_last = (rem + a.vec_rows - 1) / a.vec_rows * a.vec_rows;
     T *dst = (T *)a.panel + a.tile_pbase[c];
     int *oidx = a.index + a.tile_ibase[c] + b.vcol;
-    const T *src = (const T *)a.arena + b.tmp_v + (coff - b.s_off);
+    T *src = (T *)const_cast<void *>(a.arena) + b.tmp_v + (coff - b.s_off);
     const int p = c - b.v_tile0;
     const int total = b.rank * cs;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int j = e / b.rank, k = e - j * b.rank;
         int rr = b.vcol + k, q = rr / TM, rl = rr - q * TM;
         int ld = (q == nq - 1) ? ld_last : TM;
-        dst[(long long)q * cs * TM + (long long)j * ld + rl] = src[(long long)k * b.n + j];
+        const long long di = (long long)q * cs * TM + (long long)j * ld + rl;
+        if (REVERSE) { src[(long long)k * b.n + j] = dst[di]; continue; }
+        dst[di] = src[(long long)k * b.n + j];
         if (j == 0) oidx[k] = (int)(b.v_obase + (long long)p * b.v_ostride + k);
     }
 }
@@ -520,15 +528,26 @@ struct DeviceBuilder {
         d_ct_off = upload(H.ctiles.off);
         d_ct_size = upload(H.ctiles.size);
     }
+    // attach to an existing device H-matrix (recompression re-packs its batches in place)
+    DeviceBuilder(HMatrix &h, DeviceHMatrix *existing) : H(h), D(existing) {
+        require_device();
+        HIP_OK(hipSetDevice(D->device));
+        vec_rows = H.is_complex ? 1 : 2;
+        d_rt_off = upload(H.rtiles.off);
+        d_rt_size = upload(H.rtiles.size);
+        d_ct_off = upload(H.ctiles.off);
+        d_ct_size = upload(H.ctiles.size);
+    }
     ~DeviceBuilder() {
         (void)hipFree(d_rt_off); (void)hipFree(d_rt_size); (void)hipFree(d_ct_off); (void)hipFree(d_ct_size);
     }
 
     // pack one batch whose leaf panels sit in d_arena (device)
+    // replace_index >= 0: the new panels take the place of an existing batch (whose buffers are freed)
     template <typename T>
-    void pack_batch(const std::vector<int64_t> &batch_blocks, const void *d_arena, bool eval_dense) {
+    void pack_batch(const std::vector<int64_t> &batch_blocks, const void *d_arena, bool eval_dense, int replace_index = -1) {
         BatchLayout L;
-        L.batch_id = (int)D->batches.size();
+        L.batch_id = replace_index >= 0 ? replace_index : (int)D->batches.size();
         double tl0 = wall_seconds();
         compute_batch_layout(H, batch_blocks, vec_rows, L);
         double tl1 = wall_seconds();
@@ -554,22 +573,75 @@ struct DeviceBuilder {
         // U / dense side
         a.item_block = d_ub; a.item_tile = d_ut; a.tile_off = d_rt_off; a.tile_size = d_rt_size; a.tile_n = d_bn;
         a.tile_pbase = d_bp; a.tile_ibase = d_bc; a.panel = B.panelB; a.index = B.cidxB;
-        if (!L.u_item_block.empty()) hipLaunchKernelGGL(pack_u_kernel<T>, dim3((unsigned)L.u_item_block.size()), dim3(256), 0, D->stream, a);
+        if (!L.u_item_block.empty()) hipLaunchKernelGGL((pack_u_kernel<T, false>), dim3((unsigned)L.u_item_block.size()), dim3(256), 0, D->stream, a);
         // V side
         a.item_block = d_vb; a.item_tile = d_vt; a.tile_off = d_ct_off; a.tile_size = d_ct_size; a.tile_n = d_an;
         a.tile_pbase = d_ap; a.tile_ibase = d_ao; a.panel = B.panelA; a.index = B.oidxA;
-        if (!L.v_item_block.empty()) hipLaunchKernelGGL(pack_v_kernel<T>, dim3((unsigned)L.v_item_block.size()), dim3(256), 0, D->stream, a);
+        if (!L.v_item_block.empty()) hipLaunchKernelGGL((pack_v_kernel<T, false>), dim3((unsigned)L.v_item_block.size()), dim3(256), 0, D->stream, a);
         HIP_OK(hipGetLastError());
         double tl2 = wall_seconds();
         HIP_OK(hipStreamSynchronize(D->stream));
         log_message(LOG_DEBUG, strprintf("pack batch %d: layout %.3f s, alloc+upload %.3f s, kernels %.3f s, panels %.2f GB", L.batch_id, tl1 - tl0, tl2 - tl1, wall_seconds() - tl2, (szA + szB) / 1e9));
         for (void *p : {(void *)d_blocks, (void *)d_ub, (void *)d_ut, (void *)d_vb, (void *)d_vt, (void *)d_bn, (void *)d_an, (void *)d_bp, (void *)d_bc, (void *)d_ap, (void *)d_ao}) (void)hipFree(p);
-        D->batches.push_back(B);
         BatchTables bt;
         bt.b_ncols.swap(L.b_ncols); bt.a_nrows.swap(L.a_nrows);
         bt.b_pbase.swap(L.b_pbase); bt.b_cbase.swap(L.b_cbase); bt.a_pbase.swap(L.a_pbase); bt.a_obase.swap(L.a_obase);
         bt.reduces.swap(L.reduces);
-        D->tabs.push_back(std::move(bt));
+        if (replace_index >= 0) {
+            DevBatch &old = D->batches[replace_index];
+            (void)hipFree(old.panelB); (void)hipFree(old.panelA); (void)hipFree(old.cidxB); (void)hipFree(old.oidxA);
+            old = B;
+            D->tabs[replace_index] = std::move(bt);
+        } else {
+            D->batches.push_back(B);
+            D->tabs.push_back(std::move(bt));
+        }
+    }
+
+    // bulk unpack: copy the panels of the given leaves of batch `bidx` back into an arena (tmp_u / tmp_v of the
+    // blocks say where); the inverse of pack_batch, driven by the batch's stored tables
+    template <typename T>
+    void unpack_batch(const std::vector<int64_t> &batch_blocks, int bidx, void *d_arena) {
+        const BatchTables &bt = D->tabs[bidx];
+        std::vector<DevBlock> hb(batch_blocks.size());
+        std::vector<int> ub, ut, vb, vt;
+        for (size_t q = 0; q < batch_blocks.size(); q++) {
+            const BlockRec &b = H.blocks[batch_blocks[q]];
+            hb[q] = to_dev(b, H);
+            for (int r = H.rtiles.node_tile_begin[b.t_node]; r < H.rtiles.node_tile_end[b.t_node]; r++) { ub.push_back((int)q); ut.push_back(r); }
+            if (b.rank >= 0)
+                for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) { vb.push_back((int)q); vt.push_back(c); }
+        }
+        DevBlock *d_blocks = upload(hb);
+        int *d_ub = upload(ub), *d_ut = upload(ut), *d_vb = upload(vb), *d_vt = upload(vt), *d_an = upload(bt.a_nrows);
+        std::vector<long long> t1(bt.b_pbase.begin(), bt.b_pbase.end()), t3(bt.a_pbase.begin(), bt.a_pbase.end());
+        long long *d_bp = upload(t1), *d_ap = upload(t3);
+        PackArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.blocks = d_blocks; a.arena = d_arena; a.vec_rows = vec_rows; a.tile_max = H.tile_max; a.col_off = H.col_off;
+        a.item_block = d_ub; a.item_tile = d_ut; a.tile_off = d_rt_off; a.tile_size = d_rt_size; a.tile_pbase = d_bp; a.tile_ibase = d_bp;
+        a.panel = D->batches[bidx].panelB; a.index = D->batches[bidx].cidxB;
+        if (!ub.empty()) hipLaunchKernelGGL((pack_u_kernel<T, true>), dim3((unsigned)ub.size()), dim3(256), 0, D->stream, a);
+        a.item_block = d_vb; a.item_tile = d_vt; a.tile_off = d_ct_off; a.tile_size = d_ct_size; a.tile_n = d_an; a.tile_pbase = d_ap; a.tile_ibase = d_ap;
+        a.panel = D->batches[bidx].panelA; a.index = D->batches[bidx].oidxA;
+        if (!vb.empty()) hipLaunchKernelGGL((pack_v_kernel<T, true>), dim3((unsigned)vb.size()), dim3(256), 0, D->stream, a);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipStreamSynchronize(D->stream));
+        for (void *p : {(void *)d_blocks, (void *)d_ub, (void *)d_ut, (void *)d_vb, (void *)d_vt, (void *)d_an, (void *)d_bp, (void *)d_ap}) (void)hipFree(p);
+    }
+
+    // drop W and the product tables (they are rebuilt by assemble())
+    void free_product_tables() {
+        for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->tilesB_split,
+                        (void *)D->perm_s, (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, D->ypart})
+            if (p) (void)hipFree(p);
+        D->segs = nullptr; D->tilesB_user = D->tilesB_cluster = D->tilesA = D->tilesA2 = D->tilesB_split = nullptr;
+        D->perm_s = D->perm_t = D->iota = D->ones_idx = nullptr;
+        D->W = D->x_tmp = D->y_tmp = D->ypart = nullptr;
+        D->nB = D->nA = D->nA2 = D->nB_split = 0;
+        D->splitB = 1;
+        D->rhs_cap = 0;
+        D->table_bytes = 0;
     }
 
     // build W, the permutation tables and the tile/segment tables of the three product phases
@@ -1085,3 +1157,4 @@ void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *Bout) {
 } // namespace hm
 
 #include "device_build.inc"
+#include "device_recompress.inc"

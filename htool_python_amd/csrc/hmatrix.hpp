@@ -142,6 +142,7 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y);              
 void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream);
 void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream);
 void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y);
+int64_t device_recompress(HMatrix &H, double eps);
 void device_clone(const HMatrix &src, HMatrix &dst);
 void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *B);
 int64_t device_resident_bytes(const HMatrix &H);

@@ -495,10 +495,23 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
             }, "x_ptr"_a, "ldx"_a, "y_ptr"_a, "ldy"_a, "mu"_a, "numbering"_a = 0, "stream"_a = 0)
         .def_property_readonly("_handle", [](const H &s) { return (std::uintptr_t)s.h; });
 
-    m.def("recompression", [](H &) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
-    m.def("recompression", [](H &, py::object) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
-    m.def("openmp_recompression", [](H &) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
-    m.def("openmp_recompression", [](H &, py::object) { python_log_sink(2, "recompression is outside the MI355X hot path; H-matrix left unchanged"); });
+    // recompression / openmp_recompression (hmatrix/hmatrix.hpp:96-99): SVD recompression on the device; the variant
+    // taking a Python callable per low-rank matrix has no device counterpart and falls back to the built-in rule
+    auto recompress = [](H &s) {
+        int64_t n = 0;
+        check(htool_hmatrix_recompress(s.h, -1.0, &n));
+        return n;
+    };
+    m.def("recompression", [recompress](H &s) { return recompress(s); });
+    m.def("recompression", [recompress](H &s, py::object) {
+        python_log_sink(2, "recompression(hmatrix, fn): user-defined recompression callables are not supported on the HIP path; using the built-in SVD rule");
+        return recompress(s);
+    });
+    m.def("openmp_recompression", [recompress](H &s) { return recompress(s); });
+    m.def("openmp_recompression", [recompress](H &s, py::object) {
+        python_log_sink(2, "openmp_recompression(hmatrix, fn): user-defined recompression callables are not supported on the HIP path; using the built-in SVD rule");
+        return recompress(s);
+    });
 
     // HMatrixTreeBuilder (hmatrix/hmatrix_tree_builder.hpp:10-44)
     typedef PyHMatrixTreeBuilder<T> B;

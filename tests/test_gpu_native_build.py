@@ -270,3 +270,66 @@ def test_config_c1_use_hmatrix_10k(built, oracle, kind, p0, symmetry, uplo):
     Y = H @ X
     Ye = O.dense_matvec(kind, pts, pts, X, p0)
     assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < eps
+
+
+@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("eps,leaf", [(1e-3, 50), (1e-5, 16)])
+def test_recompression(built, oracle, native, eps, leaf):
+    """Htool.recompression(hmatrix) (src/htool/hmatrix/hmatrix.hpp:96-99): SVD recompression of the low-rank leaves
+    on the device.  Ranks shrink to (about) the numpy-SVD truncation of the SAME panels under the rule of
+    example/advanced/define_custom_low_rank_generator.py:16-24, the product stays within epsilon of the exact
+    operator, dense leaves are untouched, and the re-packed operator still equals the CPU leaf loop on its panels."""
+    import copy
+
+    import Htool
+    from tests.helpers import NumpyGenerator, cluster_of, cpu_leaf_loop
+
+    O = oracle
+    n = 4000
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, leaf)
+    gen = Htool.NativeGenerator("laplace", pts, pts) if native else NumpyGenerator(pts, pts, O.K_LAPLACE, 0.0)
+    H = Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N").build(gen, cl, cl)
+    H0 = copy.deepcopy(H)
+    L0 = np.asarray(H0.leaves())
+    reduced = Htool.recompression(H)
+    L1 = np.asarray(H.leaves())
+    assert np.array_equal(L0[:, :4], L1[:, :4]) and np.all(L1[:, 4] <= L0[:, 4])
+    assert np.array_equal(L1[L0[:, 4] < 0, 4], L0[L0[:, 4] < 0, 4])  # dense leaves stay dense
+    assert reduced == int((L1[:, 4] < L0[:, 4]).sum()) and reduced > 0.3 * (L0[:, 4] > 1).sum()
+    x = np.random.rand(n)
+    ye = O.dense_matvec(O.K_LAPLACE, pts, pts, x)
+    y = H * x
+    assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < eps
+    assert np.linalg.norm(y - cpu_leaf_loop(H, x)) / np.linalg.norm(y) < 1e-12
+    # leaf by leaf against numpy's SVD truncation of the ORIGINAL panels
+    rng = np.random.RandomState(1)
+    lr = np.flatnonzero(L0[:, 4] >= 2)
+    same = 0
+    sel = rng.choice(lr, 60, replace=False)
+    for i in sel:
+        U0, V0 = (np.asarray(a) for a in H0.leaf_panels(int(i)))
+        U1, V1 = (np.asarray(a) for a in H.leaf_panels(int(i)))
+        A0 = U0 @ V0
+        s = np.linalg.svd(A0, compute_uv=False)[: U0.shape[1]]
+        tot = (s ** 2).sum()
+        r_ref = len(s)
+        while r_ref > 1 and (s[r_ref - 1:] ** 2).sum() <= eps * eps * tot:
+            r_ref -= 1
+        same += int(U1.shape[1] == r_ref)
+        assert abs(U1.shape[1] - r_ref) <= 1
+        assert np.linalg.norm(U1 @ V1 - A0) <= 1.05 * eps * np.linalg.norm(A0)
+    assert same >= 0.9 * len(sel)
+    # the untouched copy still multiplies like before; a second pass changes (almost) nothing
+    assert np.linalg.norm(H0 * x - ye) / np.linalg.norm(ye) < eps
+    # a second pass truncates the already truncated leaves once more (each pass may discard up to eps^2 of a
+    # leaf's energy): fewer leaves change, and the product stays within 2 eps
+    again = Htool.openmp_recompression(H)
+    assert again < reduced
+    assert np.linalg.norm(H * x - ye) / np.linalg.norm(ye) < 2 * eps
+    if native:
+        X = np.asfortranarray(np.random.rand(n, 3))
+        Y = H @ X
+        for c in range(3):
+            assert np.array_equal(Y[:, c], H * np.ascontiguousarray(X[:, c]))
