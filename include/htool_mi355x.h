@@ -128,8 +128,8 @@ int htool_hmatrix_build_local(const htool_generator *g, const htool_cluster *tar
 void htool_hmatrix_destroy(htool_hmatrix *h);
 int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out); /* __deepcopy__, hmatrix.hpp:48 */
 /* htool::recompression (hmatrix.hpp:96-99): SVD recompression of the low-rank leaves, on the device, in place
- * (panels re-packed; leaf ranks shrink).  epsilon <= 0 uses the builder's epsilon.  Real operators with
- * epsilon >= 1e-7; anything else is left unchanged (a WARNING is logged).  n_reduced: leaves whose rank decreased. */
+ * (panels re-packed; leaf ranks shrink).  epsilon <= 0 uses the builder's epsilon.  Applies for
+ * epsilon >= 1e-7 (tighter tolerances are left unchanged, a WARNING is logged).  n_reduced: leaves whose rank decreased. */
 int htool_hmatrix_recompress(htool_hmatrix *h, double epsilon, int64_t *n_reduced);
 int htool_hmatrix_is_complex(const htool_hmatrix *h);
 int htool_hmatrix_nb_rows(const htool_hmatrix *h); /* hmatrix.hpp:31: size of the target cluster it was built on */

@@ -333,3 +333,45 @@ def test_recompression(built, oracle, native, eps, leaf):
         Y = H @ X
         for c in range(3):
             assert np.array_equal(Y[:, c], H * np.ascontiguousarray(X[:, c]))
+
+
+def test_recompression_complex(built, oracle):
+    """Same as test_recompression for a complex operator (Helmholtz): ranks against numpy's SVD truncation of the
+    original panels, leaf accuracy, product accuracy, re-packed panels consistent with the CPU leaf loop."""
+    import copy
+
+    import Htool
+    from tests.helpers import cluster_of, cpu_leaf_loop
+
+    O = oracle
+    n, eps, kappa = 4000, 1e-4, 6.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 24)
+    H = Htool.ComplexHMatrixTreeBuilder(eps, 10.0, "N", "N").build(Htool.ComplexNativeGenerator("helmholtz", pts, pts, kappa), cl, cl)
+    H0 = copy.deepcopy(H)
+    L0 = np.asarray(H0.leaves())
+    reduced = Htool.recompression(H)
+    L1 = np.asarray(H.leaves())
+    assert reduced == int((L1[:, 4] < L0[:, 4]).sum()) and reduced > 0.3 * (L0[:, 4] > 1).sum()
+    x = np.random.rand(n) + 1j * np.random.rand(n)
+    ye = O.dense_matvec(O.K_HELMHOLTZ, pts, pts, x, kappa)
+    y = H * x
+    assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < eps
+    assert np.linalg.norm(y - cpu_leaf_loop(H, x, True)) / np.linalg.norm(y) < 1e-12
+    rng = np.random.RandomState(1)
+    sel = rng.choice(np.flatnonzero(L0[:, 4] >= 2), 50, replace=False)
+    same = 0
+    for i in sel:
+        U0, V0 = (np.asarray(a) for a in H0.leaf_panels(int(i)))
+        U1, V1 = (np.asarray(a) for a in H.leaf_panels(int(i)))
+        A0 = U0 @ V0
+        s = np.linalg.svd(A0, compute_uv=False)[: U0.shape[1]]
+        tot = (s ** 2).sum()
+        r_ref = len(s)
+        while r_ref > 1 and (s[r_ref - 1:] ** 2).sum() <= eps * eps * tot:
+            r_ref -= 1
+        same += int(U1.shape[1] == r_ref)
+        assert abs(U1.shape[1] - r_ref) <= 1
+        assert np.linalg.norm(U1 @ V1 - A0) <= 1.05 * eps * np.linalg.norm(A0)
+    assert same >= 0.9 * len(sel)
