@@ -491,6 +491,27 @@ static V *upload(const std::vector<V> &h, size_t *bytes = nullptr) {
     return d;
 }
 
+// scope guard for temporary device buffers (freed on every exit path, exceptions included)
+struct TempPool {
+    std::vector<void *> ptrs;
+    template <typename V>
+    V *up(const std::vector<V> &h) {
+        V *d = upload(h);
+        ptrs.push_back((void *)d);
+        return d;
+    }
+    void *alloc(size_t bytes) {
+        void *d = nullptr;
+        HIP_OK(hipMalloc(&d, std::max<size_t>(bytes, 1)));
+        ptrs.push_back(d);
+        return d;
+    }
+    void release(void *p) { // free one buffer early
+        for (auto &q : ptrs) if (q == p) { (void)hipFree(q); q = nullptr; }
+    }
+    ~TempPool() { for (void *p : ptrs) if (p) (void)hipFree(p); }
+};
+
 static DevBlock to_dev(const BlockRec &b, const HMatrix &H) {
     DevBlock d;
     d.tmp_u = b.tmp_u; d.tmp_v = b.tmp_v; d.tpos = b.tpos; d.v_obase = b.v_obase;
@@ -554,19 +575,21 @@ struct DeviceBuilder {
         for (int64_t bi : batch_blocks) H.blocks[bi].batch = L.batch_id;
         DevBatch B;
         size_t szB = std::max<int64_t>(L.panelB_elems, 1) * sizeof(T), szA = std::max<int64_t>(L.panelA_elems, 1) * sizeof(T);
-        HIP_OK(hipMalloc(&B.panelB, szB));
-        HIP_OK(hipMalloc(&B.panelA, szA));
-        HIP_OK(hipMalloc((void **)&B.cidxB, std::max<int64_t>(L.cidxB_elems, 1) * sizeof(int)));
-        HIP_OK(hipMalloc((void **)&B.oidxA, std::max<int64_t>(L.oidxA_elems, 1) * sizeof(int)));
+        TempPool owned; // the batch's own buffers, handed over to D at the end
+        B.panelB = owned.alloc(szB);
+        B.panelA = owned.alloc(szA);
+        B.cidxB = (int *)owned.alloc(std::max<int64_t>(L.cidxB_elems, 1) * sizeof(int));
+        B.oidxA = (int *)owned.alloc(std::max<int64_t>(L.oidxA_elems, 1) * sizeof(int));
         B.bytes = szB + szA + (L.cidxB_elems + L.oidxA_elems) * sizeof(int);
         std::vector<DevBlock> hb(batch_blocks.size());
         for (size_t q = 0; q < batch_blocks.size(); q++) hb[q] = to_dev(H.blocks[batch_blocks[q]], H);
-        DevBlock *d_blocks = upload(hb);
-        int *d_ub = upload(L.u_item_block), *d_ut = upload(L.u_item_tile), *d_vb = upload(L.v_item_block), *d_vt = upload(L.v_item_tile);
-        int *d_bn = upload(L.b_ncols), *d_an = upload(L.a_nrows);
+        TempPool tmp;
+        DevBlock *d_blocks = tmp.up(hb);
+        int *d_ub = tmp.up(L.u_item_block), *d_ut = tmp.up(L.u_item_tile), *d_vb = tmp.up(L.v_item_block), *d_vt = tmp.up(L.v_item_tile);
+        int *d_bn = tmp.up(L.b_ncols), *d_an = tmp.up(L.a_nrows);
         std::vector<long long> t1(L.b_pbase.begin(), L.b_pbase.end()), t2(L.b_cbase.begin(), L.b_cbase.end());
         std::vector<long long> t3(L.a_pbase.begin(), L.a_pbase.end()), t4(L.a_obase.begin(), L.a_obase.end());
-        long long *d_bp = upload(t1), *d_bc = upload(t2), *d_ap = upload(t3), *d_ao = upload(t4);
+        long long *d_bp = tmp.up(t1), *d_bc = tmp.up(t2), *d_ap = tmp.up(t3), *d_ao = tmp.up(t4);
         PackArgs a;
         a.blocks = d_blocks; a.arena = d_arena; a.vec_rows = vec_rows; a.tile_max = H.tile_max; a.col_off = H.col_off;
         a.eval_dense = eval_dense ? 1 : 0; a.gen = gen;
@@ -582,11 +605,11 @@ struct DeviceBuilder {
         double tl2 = wall_seconds();
         HIP_OK(hipStreamSynchronize(D->stream));
         log_message(LOG_DEBUG, strprintf("pack batch %d: layout %.3f s, alloc+upload %.3f s, kernels %.3f s, panels %.2f GB", L.batch_id, tl1 - tl0, tl2 - tl1, wall_seconds() - tl2, (szA + szB) / 1e9));
-        for (void *p : {(void *)d_blocks, (void *)d_ub, (void *)d_ut, (void *)d_vb, (void *)d_vt, (void *)d_bn, (void *)d_an, (void *)d_bp, (void *)d_bc, (void *)d_ap, (void *)d_ao}) (void)hipFree(p);
         BatchTables bt;
         bt.b_ncols.swap(L.b_ncols); bt.a_nrows.swap(L.a_nrows);
         bt.b_pbase.swap(L.b_pbase); bt.b_cbase.swap(L.b_cbase); bt.a_pbase.swap(L.a_pbase); bt.a_obase.swap(L.a_obase);
         bt.reduces.swap(L.reduces);
+        owned.ptrs.clear(); // success: ownership moves to the device H-matrix
         if (replace_index >= 0) {
             DevBatch &old = D->batches[replace_index];
             (void)hipFree(old.panelB); (void)hipFree(old.panelA); (void)hipFree(old.cidxB); (void)hipFree(old.oidxA);
@@ -612,10 +635,11 @@ struct DeviceBuilder {
             if (b.rank >= 0)
                 for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) { vb.push_back((int)q); vt.push_back(c); }
         }
-        DevBlock *d_blocks = upload(hb);
-        int *d_ub = upload(ub), *d_ut = upload(ut), *d_vb = upload(vb), *d_vt = upload(vt), *d_an = upload(bt.a_nrows);
+        TempPool tmp;
+        DevBlock *d_blocks = tmp.up(hb);
+        int *d_ub = tmp.up(ub), *d_ut = tmp.up(ut), *d_vb = tmp.up(vb), *d_vt = tmp.up(vt), *d_an = tmp.up(bt.a_nrows);
         std::vector<long long> t1(bt.b_pbase.begin(), bt.b_pbase.end()), t3(bt.a_pbase.begin(), bt.a_pbase.end());
-        long long *d_bp = upload(t1), *d_ap = upload(t3);
+        long long *d_bp = tmp.up(t1), *d_ap = tmp.up(t3);
         PackArgs a;
         std::memset(&a, 0, sizeof(a));
         a.blocks = d_blocks; a.arena = d_arena; a.vec_rows = vec_rows; a.tile_max = H.tile_max; a.col_off = H.col_off;
@@ -627,7 +651,6 @@ struct DeviceBuilder {
         if (!vb.empty()) hipLaunchKernelGGL((pack_v_kernel<T, true>), dim3((unsigned)vb.size()), dim3(256), 0, D->stream, a);
         HIP_OK(hipGetLastError());
         HIP_OK(hipStreamSynchronize(D->stream));
-        for (void *p : {(void *)d_blocks, (void *)d_ub, (void *)d_ut, (void *)d_vb, (void *)d_vt, (void *)d_an, (void *)d_bp, (void *)d_ap}) (void)hipFree(p);
     }
 
     // drop W and the product tables (they are rebuilt by assemble())
@@ -1122,26 +1145,26 @@ void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *Bout) {
     const int vec_rows = H.is_complex ? 1 : 2;
     const BatchTables &L = D->tabs[b.batch];
     std::vector<DevBlock> hb{to_dev(b, H)};
-    DevBlock *d_b = upload(hb);
+    TempPool tmp;
+    DevBlock *d_b = tmp.up(hb);
     PackArgs a;
     std::memset(&a, 0, sizeof(a));
     a.blocks = d_b; a.vec_rows = vec_rows; a.tile_max = H.tile_max;
     std::vector<int> ut, vt;
     for (int r = H.rtiles.node_tile_begin[b.t_node]; r < H.rtiles.node_tile_end[b.t_node]; r++) ut.push_back(r);
     if (b.rank > 0) for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) vt.push_back(c);
-    int *d_ut = upload(ut), *d_vt = upload(vt);
-    int *d_rto = upload(H.rtiles.off), *d_rts = upload(H.rtiles.size), *d_cto = upload(H.ctiles.off), *d_cts = upload(H.ctiles.size);
+    int *d_ut = tmp.up(ut), *d_vt = tmp.up(vt);
+    int *d_rto = tmp.up(H.rtiles.off), *d_rts = tmp.up(H.rtiles.size), *d_cto = tmp.up(H.ctiles.off), *d_cts = tmp.up(H.ctiles.size);
     std::vector<long long> t1(L.b_pbase.begin(), L.b_pbase.end()), t3(L.a_pbase.begin(), L.a_pbase.end());
-    long long *d_bp = upload(t1), *d_ap = upload(t3);
-    int *d_an = upload(L.a_nrows);
+    long long *d_bp = tmp.up(t1), *d_ap = tmp.up(t3);
+    int *d_an = tmp.up(L.a_nrows);
     const int ncolsU = b.rank >= 0 ? b.rank : b.n;
-    void *d_outA = nullptr, *d_outB = nullptr;
-    HIP_OK(hipMalloc(&d_outA, (size_t)b.m * ncolsU * es));
+    void *d_outA = tmp.alloc((size_t)b.m * ncolsU * es), *d_outB = nullptr;
     a.item_tile = d_ut; a.tile_off = d_rto; a.tile_size = d_rts; a.tile_pbase = d_bp; a.panel = D->batches[b.batch].panelB;
     if (H.is_complex) hipLaunchKernelGGL(unpack_u_kernel<double2>, dim3((unsigned)ut.size()), dim3(256), 0, D->stream, a, (double2 *)d_outA);
     else hipLaunchKernelGGL(unpack_u_kernel<double>, dim3((unsigned)ut.size()), dim3(256), 0, D->stream, a, (double *)d_outA);
     if (b.rank > 0) {
-        HIP_OK(hipMalloc(&d_outB, (size_t)b.n * b.rank * es));
+        d_outB = tmp.alloc((size_t)b.n * b.rank * es);
         a.item_tile = d_vt; a.tile_off = d_cto; a.tile_size = d_cts; a.tile_pbase = d_ap; a.tile_n = d_an; a.panel = D->batches[b.batch].panelA;
         if (H.is_complex) hipLaunchKernelGGL(unpack_v_kernel<double2>, dim3((unsigned)vt.size()), dim3(256), 0, D->stream, a, (double2 *)d_outB);
         else hipLaunchKernelGGL(unpack_v_kernel<double>, dim3((unsigned)vt.size()), dim3(256), 0, D->stream, a, (double *)d_outB);
@@ -1150,8 +1173,6 @@ void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *Bout) {
     HIP_OK(hipStreamSynchronize(D->stream));
     HIP_OK(hipMemcpy(A, d_outA, (size_t)b.m * ncolsU * es, hipMemcpyDeviceToHost));
     if (b.rank > 0) HIP_OK(hipMemcpy(Bout, d_outB, (size_t)b.n * b.rank * es, hipMemcpyDeviceToHost));
-    for (void *p : {(void *)d_b, (void *)d_ut, (void *)d_vt, (void *)d_rto, (void *)d_rts, (void *)d_cto, (void *)d_cts, (void *)d_bp, (void *)d_ap, (void *)d_an, d_outA, d_outB})
-        if (p) (void)hipFree(p);
 }
 
 } // namespace hm
