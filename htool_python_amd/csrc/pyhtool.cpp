@@ -245,7 +245,12 @@ struct PyHMatrix {
         py::array_t<T, py::array::f_style> result(htool_hmatrix_nb_rows(h));
         std::fill_n(result.mutable_data(), result.size(), T(0));
         T one(1), zero(0);
-        check(htool_hmatrix_matvec(h, 'N', &one, input.data(), &zero, result.mutable_data()));
+        int rc;
+        {
+            py::gil_scoped_release nogil; // no Python code runs inside a product (the log sink re-acquires the GIL itself)
+            rc = htool_hmatrix_matvec(h, 'N', &one, input.data(), &zero, result.mutable_data());
+        }
+        check(rc);
         return result;
     }
     py::array_t<T, py::array::f_style> matmul(const py::array_t<T, py::array::f_style> &input) const {
@@ -254,7 +259,12 @@ struct PyHMatrix {
         py::array_t<T, py::array::f_style> result({(py::ssize_t)htool_hmatrix_nb_rows(h), input.shape(1)});
         std::fill_n(result.mutable_data(), result.size(), T(0));
         T one(1), zero(0);
-        check(htool_hmatrix_matmat(h, 'N', &one, input.data(), (int)input.shape(1), &zero, result.mutable_data()));
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = htool_hmatrix_matmat(h, 'N', &one, input.data(), (int)input.shape(1), &zero, result.mutable_data());
+        }
+        check(rc);
         return result;
     }
     py::array_t<T, py::array::f_style> dense(bool user) const {
@@ -290,7 +300,15 @@ struct PyHMatrixTreeBuilder {
         H.target = target;
         H.source = source;
         htool_build_params q = resolved();
-        check(htool_hmatrix_build(generator.get(), target.owner->root, source.owner->root, &q, target_partition_number, partition_number_for_symmetry, &H.h));
+        htool_generator *g = generator.get();
+        int rc;
+        if (dynamic_cast<PyNativeGenerator<T> *>(&generator) && !low_rank && !dense_blocks) {
+            py::gil_scoped_release nogil; // native generator: nothing calls back into Python during the build
+            rc = htool_hmatrix_build(g, target.owner->root, source.owner->root, &q, target_partition_number, partition_number_for_symmetry, &H.h);
+        } else { // callback generators / hooks run Python code on this thread: keep the GIL (CMakeLists.txt:97 rationale)
+            rc = htool_hmatrix_build(g, target.owner->root, source.owner->root, &q, target_partition_number, partition_number_for_symmetry, &H.h);
+        }
+        check(rc);
         return H;
     }
 };
