@@ -222,3 +222,46 @@ def test_tiles_partition_rows_and_align_with_clusters(built, tile_max):
     sub = np.asarray(Htool.cluster_tiles(cl, 1, tile_max))
     p1 = cl.get_cluster_on_partition(1)
     assert sub[0, 0] == p1.get_offset() and sub[:, 1].sum() == p1.get_size()
+
+
+@pytest.mark.parametrize("dimension", [2, 3])
+def test_cluster_plot_runs(built, dimension):
+    """tests/test_cluster.py:37-42: Htool.plot(ax, cluster, points, depth) for the root and for a partition."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    import Htool
+
+    pts = np.random.RandomState(5).rand(dimension, 500)
+    b = Htool.ClusterTreeBuilder()
+    cl = b.create_cluster_tree(pts, 2, size_of_partition=2)
+    local = cl.get_cluster_on_partition(1)
+    fig = plt.figure()
+    kw = {"projection": "3d"} if dimension == 3 else {}
+    axes = [fig.add_subplot(2, 2, i + 1, **kw) for i in range(4)]
+    Htool.plot(axes[0], cl, pts, 1)
+    Htool.plot(axes[1], cl, pts, 2)
+    Htool.plot(axes[2], local, pts, 1)
+    Htool.plot(axes[3], local, pts, 2)
+    # depth-1 colouring of the root = the two partitions
+    assert len(np.unique(np.asarray(axes[0].collections[0].get_array()))) == 2
+    # the partition sub-tree only draws its own points
+    n_local = axes[2].collections[0].get_offsets().shape[0] if dimension == 2 else len(axes[2].collections[0]._offsets3d[0])
+    assert n_local == local.get_size()
+    plt.close(fig)
+
+
+def test_mpi4py_standin_world_of_one(built):
+    import mpi4py
+
+    comm = mpi4py.MPI.COMM_WORLD
+    assert comm.size == comm.Get_size() == 1 and comm.rank == comm.Get_rank() == 0
+    assert comm.allreduce(7, op=mpi4py.MPI.SUM) == 7
+    send = np.arange(5, dtype=np.uint8)
+    recv = np.zeros(5, dtype=np.uint8)
+    comm._htool_allgatherv(send, recv, [5], [0])
+    assert np.array_equal(send, recv)
+    comm.Barrier()
+    assert comm.bcast("x") == "x"
