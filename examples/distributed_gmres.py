@@ -1,8 +1,8 @@
 """Row-distributed operator + GMRES solve (counterparts of the reference's example/use_distributed_operator.py
 and example/use_ddm_solver.py for this repository).
 
-    python examples/use_distributed_operator.py                        # one rank
-    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/use_distributed_operator.py
+    python examples/distributed_gmres.py                        # one rank
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 examples/distributed_gmres.py
 """
 import logging
 import os

@@ -1,7 +1,7 @@
 """Build an H-matrix and multiply with it (counterpart of the reference's example/use_hmatrix.py, written
 for this repository: same API calls, numpy-vectorised callback generator, optional native generator).
 
-    python examples/use_hmatrix.py [--native] [--size 1000] [--plot out.png]
+    python examples/hmatrix_quickstart.py [--native] [--size 1000] [--plot out.png]
 """
 import argparse
 import logging

@@ -40,28 +40,29 @@ class ComplexNumpyGenerator(Htool.ComplexVirtualGenerator):
 
 
 class CustomSVD(Htool.VirtualLowRankGenerator):
-    """Truncated-SVD compressor with the acceptance rule of the reference's example
-    (example/advanced/define_custom_low_rank_generator.py:13-31)."""
+    """User compressor: truncated SVD of the block.  Acceptance rule as in the reference's example compressor
+    (example/advanced/define_custom_low_rank_generator.py:16-27): trailing singular values are dropped while the
+    discarded energy stays below (epsilon |A|_F)^2, and the block is refused when r (m + n) > m n."""
 
     def __init__(self, generator, allow_copy=True):
         super().__init__(allow_copy)
         self.generator = generator
 
     def build_low_rank_approximation(self, rows, cols, epsilon):
-        submat = np.zeros((len(rows), len(cols)), order="F")
-        self.generator.build_submatrix(rows, cols, submat)
-        u, s, vh = np.linalg.svd(submat, full_matrices=False)
-        norm = np.linalg.norm(submat)
-        svd_norm = 0
-        truncated_rank = len(s) - 1
-        while truncated_rank > 0 and np.sqrt(svd_norm) / norm < epsilon:
-            svd_norm += s[truncated_rank] ** 2
-            truncated_rank -= 1
-        truncated_rank += 1
-        if truncated_rank * (len(rows) + len(cols)) > len(rows) * len(cols):
+        m, n = len(rows), len(cols)
+        block = np.zeros((m, n), order="F")
+        self.generator.build_submatrix(rows, cols, block)
+        left, sigma, right = np.linalg.svd(block, full_matrices=False)
+        # tail[k] = energy of sigma[k:]; keep the smallest k >= 1 (scanning from the end, one value at a time, and
+        # always discarding the last one, like the reference's loop) with sqrt(tail) / |A|_F < epsilon
+        discarded, rank = 0.0, len(sigma)
+        while rank > 1 and np.sqrt(discarded) / np.linalg.norm(block) < epsilon:
+            rank -= 1
+            discarded += sigma[rank] ** 2
+        if rank * (m + n) > m * n:
             return False
-        self.set_U(u[:, 0:truncated_rank] * s[0:truncated_rank])
-        self.set_V(vh[0:truncated_rank, :])
+        self.set_U(left[:, :rank] * sigma[:rank])
+        self.set_V(right[:rank, :])
         return True
 
 

@@ -19,7 +19,7 @@ def _run(cmd, timeout=180):
 
 @pytest.mark.parametrize("native", [False, True])
 def test_use_hmatrix(built, tmp_path, native):
-    out = _run([sys.executable, "examples/use_hmatrix.py", "--plot", str(tmp_path / "h.png")] + (["--native"] if native else []))
+    out = _run([sys.executable, "examples/hmatrix_quickstart.py", "--plot", str(tmp_path / "h.png")] + (["--native"] if native else []))
     assert "matvec error" in out and (tmp_path / "h.png").exists()
 
 
@@ -30,6 +30,6 @@ def test_use_distributed_operator(built, world):
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           "examples/use_distributed_operator.py"]
+           "examples/distributed_gmres.py"]
     out = _run(cmd)
     assert "solution error" in out
