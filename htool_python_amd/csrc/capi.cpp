@@ -544,6 +544,13 @@ int htool_hmatrix_leaf_panels(const htool_hmatrix *h, int64_t leaf, void *A, voi
     API_END
 }
 
+int htool_hmatrix_leaf_panels_bulk(const htool_hmatrix *h, int64_t n, const int64_t *leaf_ids, int64_t *offsets2, void *out, int64_t *n_elements) {
+    API_BEGIN
+    int64_t e = device_leaf_panels_bulk(h->H, n, leaf_ids, offsets2, out);
+    if (n_elements) *n_elements = e;
+    API_END
+}
+
 void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8) {
     const HMatrix &H = h->H;
     int64_t dense = 0, lr = 0, nd = 0, nl = 0, sr = 0, maxr = 0;

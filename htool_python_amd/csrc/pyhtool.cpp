@@ -491,6 +491,15 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 if (r > 0) check(htool_hmatrix_leaf_panels(s.h, i, U.mutable_data(), V.mutable_data()));
                 return py::make_tuple(U, V);
             })
+        .def("leaf_panels_bulk", [](const H &s, py::array_t<int64_t, py::array::c_style | py::array::forcecast> ids) {
+                const int64_t n = ids.size();
+                py::array_t<int64_t> offs({(py::ssize_t)n, (py::ssize_t)2});
+                int64_t elems = 0;
+                check(htool_hmatrix_leaf_panels_bulk(s.h, n, ids.data(), offs.mutable_data(), nullptr, &elems));
+                py::array_t<T> out((py::ssize_t)elems);
+                check(htool_hmatrix_leaf_panels_bulk(s.h, n, ids.data(), offs.mutable_data(), out.mutable_data(), &elems));
+                return py::make_tuple(offs, out);
+            }, "leaf_ids"_a)
         .def("stats", [](const H &s) {
                 int64_t st[8];
                 htool_hmatrix_stats(s.h, st);

@@ -179,6 +179,12 @@ void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5);
  * col-major), B = V (r x n col-major).  Used by parity tests and plotting; not a hot path. */
 int htool_hmatrix_leaf_panels(const htool_hmatrix *h, int64_t leaf, void *A, void *B);
 
+/* the same for n leaves in one call: leaf q's dense block or U (column-major) starts at element offsets2[2q] of
+ * out, its V at offsets2[2q+1] stored step by step (rank rows of n_cols entries).  Pass out = NULL to obtain the
+ * offsets and the total element count first. */
+int htool_hmatrix_leaf_panels_bulk(const htool_hmatrix *h, int64_t n, const int64_t *leaf_ids, int64_t *offsets2, void *out,
+                                   int64_t *n_elements);
+
 /* get_tree_parameters / get_local_information (hmatrix.hpp:50-52): "key=value\n" lines copied
  * into buf (truncated to cap); returns needed size. which: 0 tree parameters, 1 local information */
 int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap);

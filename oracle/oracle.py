@@ -253,22 +253,9 @@ def random_geometries(dimension, nb_rows, nb_cols):
 
 
 def leaf_sample_panels(hmatrix, indices, is_complex=False):
-    """Download the panels of the given leaves of a (GPU-resident) Htool.HMatrix into the flat format
-    of leaf_loop().  Returns (leaves[k,5], offs[k,2], panels)."""
+    """Download the panels of the given leaves of a (GPU-resident) Htool.HMatrix into the flat format of
+    leaf_loop() with one bulk call.  Returns (leaves[k,5], offs[k,2], panels)."""
     L = np.asarray(hmatrix.leaves())
-    dt = np.complex128 if is_complex else np.float64
-    chunks, offs, pos, sel = [], np.zeros((len(indices), 2), dtype=np.int64), 0, []
-    for q, i in enumerate(indices):
-        A, B = hmatrix.leaf_panels(int(i))
-        a = np.asarray(A, dtype=dt).ravel(order="F")
-        offs[q, 0] = pos
-        chunks.append(a)
-        pos += a.size
-        offs[q, 1] = pos
-        if L[i, 4] >= 0:
-            v = np.ascontiguousarray(np.asarray(B, dtype=dt)).ravel()
-            chunks.append(v)
-            pos += v.size
-        sel.append(L[i])
-    panels = np.concatenate(chunks) if chunks else np.zeros(0, dtype=dt)
-    return np.asarray(sel, dtype=np.int32).reshape(-1, 5), offs, panels
+    ids = np.asarray(indices, dtype=np.int64)
+    offs, panels = hmatrix.leaf_panels_bulk(ids)
+    return np.ascontiguousarray(L[ids], dtype=np.int32).reshape(-1, 5), np.asarray(offs, dtype=np.int64), np.asarray(panels)

@@ -85,27 +85,15 @@ def cluster_of(points, max_leaf=10, children=2, **kw):
 
 
 def cpu_leaf_loop(hmatrix, x_user, is_complex=False):
-    """Download every leaf's panels from HBM and run the oracle's CPU leaf loop on them:
+    """Download every leaf's panels from HBM (one bulk call) and run the oracle's CPU leaf loop on them:
     y (user numbering) = sum over leaves, on panels IDENTICAL to what the HIP product streams."""
     leaves = np.asarray(hmatrix.leaves())
     tc, sc = hmatrix.get_target_cluster(), hmatrix.get_source_cluster()
     pt, ps = np.asarray(tc.get_permutation()), np.asarray(sc.get_permutation())
     dt = np.complex128 if is_complex else np.float64
-    chunks, offs, pos = [], np.zeros((len(leaves), 2), dtype=np.int64), 0
-    for i, (t_off, m, s_off, n, r) in enumerate(leaves):
-        A, B = hmatrix.leaf_panels(i)
-        a = np.asarray(A, dtype=dt).ravel(order="F")  # dense: m x n col-major; low rank: U m x r col-major
-        offs[i, 0] = pos
-        chunks.append(a)
-        pos += a.size
-        offs[i, 1] = pos
-        if r >= 0:
-            v = np.ascontiguousarray(np.asarray(B, dtype=dt)).ravel()  # r x n, step-major (each V row contiguous)
-            chunks.append(v)
-            pos += v.size
-    panels = np.concatenate(chunks) if chunks else np.zeros(0, dtype=dt)
+    sel, offs, panels = O.leaf_sample_panels(hmatrix, np.arange(len(leaves)), is_complex)
     xp = np.asarray(x_user, dtype=dt)[ps]
-    yp = O.leaf_loop(leaves, offs, panels, len(pt), xp, is_complex)
+    yp = O.leaf_loop(sel, offs, panels, len(pt), xp, is_complex)
     y = np.zeros(len(pt), dtype=dt)
     y[pt] = yp
     return y
