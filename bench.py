@@ -77,7 +77,7 @@ def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
     L = np.asarray(leaves, dtype=np.int64)
     size = np.where(L[:, 4] < 0, L[:, 1] * L[:, 3], L[:, 4] * (L[:, 1] + L[:, 3])) * elem_bytes
     order = rng.permutation(len(L))
-    cap_bytes, cap_leaves = 1.5e9, 12000
+    cap_bytes, cap_leaves = 8e9, 150000
     pick, tot = [], 0
     for i in order:
         if L[i, 4] == 0:
