@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--kernel", default="laplace", choices=["laplace", "inv_delta", "helmholtz"])
     ap.add_argument("--kappa", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the multi-rank code path (process group, slice exchange, "
+                                                               "cluster-numbered local product) even with a single rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the measured path; gloo stages the exchange through the host so that the "
                          "multi-rank logic can be rehearsed with several ranks on ONE GPU (not a benchmark)")
@@ -139,6 +141,11 @@ def main():
     ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
     args = ap.parse_args()
     cpu_build_sample.args = args
+    # stdout carries exactly ONE line (the JSON): libraries that chat on stdout (RCCL prints a version banner when a
+    # communicator is created) are sent to stderr by pointing fd 1 at fd 2 until the result is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -153,8 +160,12 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    dist_mode = world > 1 or args.force_dist
+    if dist_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -187,7 +198,7 @@ def main():
         builder = Htool.HMatrixTreeBuilder(args.eps, args.eta, "N", "N")
     torch.cuda.synchronize()
     t0 = time.time()
-    H = builder.build(gen, cluster, cluster, rank if world > 1 else -1)
+    H = builder.build(gen, cluster, cluster, rank if dist_mode else -1)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     t_recompress = None
@@ -203,7 +214,7 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     gen_t = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    if world == 1:
+    if not dist_mode:
         x = torch.rand(n, dtype=torch.float64, generator=gen_t)
         if is_complex:
             x = torch.complex(x, torch.rand(n, dtype=torch.float64, generator=gen_t))
@@ -242,11 +253,11 @@ def main():
         from htool_python_amd.krylov import gmres
         from htool_python_amd.solver import DeviceOperator
 
-        part = [(cluster.get_cluster_on_partition(p).get_offset(), cluster.get_cluster_on_partition(p).get_size()) for p in range(world)] if world > 1 else None
+        part = [(cluster.get_cluster_on_partition(p).get_offset(), cluster.get_cluster_on_partition(p).get_size()) for p in range(world)] if dist_mode else None
         shift = args.shift if args.shift != 0.0 else n / 50.0
         op = DeviceOperator(H, part, rank, None, shift)
         b_local = torch.rand(op.size, dtype=torch.float64, generator=gen_t).to(dtype).cuda()
-        red = op.reduce if world > 1 else None
+        red = op.reduce if dist_mode else None
         args.steps = args.gmres
 
         def run_gmres():
@@ -257,7 +268,7 @@ def main():
     for _ in range(args.warmup if step is not None else 0):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_mode:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -267,20 +278,20 @@ def main():
         for _ in range(args.steps):
             step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_mode:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_ph, ph = H.phase_times_us()
 
     tot_bytes = float(ab["total"])
-    if args.check and world > 1:
+    if args.check and dist_mode:
         # distributed result vs exact rows: gather the y slices and the x slices on every rank
         perm = np.asarray(cluster.get_permutation())
         y_user, x_user = np.zeros(n, dtype=np.complex128 if is_complex else np.float64), np.zeros(n, dtype=np.complex128 if is_complex else np.float64)
         y_user[perm] = SliceGatherer(sizes, dtype, "cuda")(y).cpu().numpy()
         x_user[perm] = SliceGatherer(sizes, dtype, "cuda")(x_local).cpu().numpy()
-    if world > 1:
+    if dist_mode:
         t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -340,13 +351,16 @@ def main():
             from oracle import oracle as O
 
             rows = np.arange(0, n, max(1, n // 256))
-            xx, yy = (x.cpu().numpy(), y.cpu().numpy()) if world == 1 else (x_user, y_user)
+            xx, yy = (x.cpu().numpy(), y.cpu().numpy()) if not dist_mode else (x_user, y_user)
             ye = O.dense_matvec({"laplace": 1, "inv_delta": 0, "helmholtz": 2}[args.kernel], pts, pts, xx, param, rows=rows)
             out["rel_err_sampled_rows"] = float(np.linalg.norm(yy[rows] - ye) / np.linalg.norm(ye))
         if world == 1 and not args.no_cpu_baseline and not is_complex:
             out["cpu_baseline"] = cpu_baseline(H, leaves, n, n, elem)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if dist_mode:
         dist.barrier()
         dist.destroy_process_group()
 
