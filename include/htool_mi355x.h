@@ -18,6 +18,8 @@
  *     available from htool_last_error() (thread-local).  The shim rethrows it as RuntimeError.
  *   - the compute path is HIP only: if no gfx950 device is usable, build/product calls FAIL
  *     (there is no CPU fallback inside the library).
+ *   - products on ONE handle are not re-entrant (they share the handle's coefficient workspace and stream
+ *     ordering is the caller's); different handles are independent.  The reference gives no stronger guarantee.
  */
 #ifndef HTOOL_MI355X_H
 #define HTOOL_MI355X_H
