@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--gmres", type=int, default=0, help="BASELINE config 5: instead of bare products, a step is ONE GMRES iteration (restart = this value) "
                                                         "on (shift I + H) with device-resident Krylov vectors")
     ap.add_argument("--shift", type=float, default=0.0, help="diagonal shift of the --gmres system (0: N/50, keeps the system well posed)")
+    ap.add_argument("--symmetric", choices=["full", "one-triangle"], default=None,
+                    help="build with symmetry 'S' / UPLO 'L' (single GPU only): 'full' stores both triangles (the default engine "
+                         "layout), 'one-triangle' stores the lower triangle only and uses every leaf twice in a fused sweep")
     ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
     args = ap.parse_args()
     cpu_build_sample.args = args
@@ -192,10 +195,13 @@ def main():
     param = {"laplace": 0.0, "inv_delta": 0.1, "helmholtz": args.kappa}[args.kernel]
     if is_complex:
         gen = Htool.ComplexNativeGenerator(args.kernel, pts, pts, param)
-        builder = Htool.ComplexHMatrixTreeBuilder(args.eps, args.eta, "N", "N")
+        builder = Htool.ComplexHMatrixTreeBuilder(args.eps, args.eta, "S" if args.symmetric else "N", "L" if args.symmetric else "N")
     else:
         gen = Htool.NativeGenerator(args.kernel, pts, pts, param)
-        builder = Htool.HMatrixTreeBuilder(args.eps, args.eta, "N", "N")
+        builder = Htool.HMatrixTreeBuilder(args.eps, args.eta, "S" if args.symmetric else "N", "L" if args.symmetric else "N")
+    if args.symmetric:
+        assert not dist_mode, "--symmetric is a single-GPU option (a row partition is not a symmetric operator)"
+        builder.set_symmetric_storage(args.symmetric == "one-triangle")
     torch.cuda.synchronize()
     t0 = time.time()
     H = builder.build(gen, cluster, cluster, rank if dist_mode else -1)
@@ -325,6 +331,7 @@ def main():
         "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,
         "rhs_per_step": args.rhs,
+        "symmetric_storage": args.symmetric,
         "gmres": None if gmres_info is None else {"iterations": gmres_info["iterations"], "s_per_iteration": dt / max(gmres_info["iterations"], 1),
                                                    "relative_residuals": [gmres_info["residuals"][i] for i in (0, len(gmres_info["residuals"]) // 2, -1)],
                                                    "note": "step = one GMRES iteration (1 product + CGS2 orthogonalisation) on (shift I + H), no preconditioner"},

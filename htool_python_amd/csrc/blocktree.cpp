@@ -9,9 +9,10 @@
 // No pointer tree is kept: a leaf is the record (t_off, m, s_off, n, rank) of
 // src/htool/matplotlib/hmatrix.hpp:18-22.
 //
-// Symmetric storage ('S'/'H' with UPLO): this engine stores BOTH triangles (the product is then a
-// plain sweep over row tiles with no transposed pass); results are identical to the reference's up
-// to the compression tolerance, memory is not halved.  See DESIGN.md "symmetry".
+// Symmetric storage ('S'/'H' with UPLO): by default this engine stores BOTH triangles (the product is
+// then a plain sweep over row tiles with no transposed pass).  With BuildParams::store_one_triangle the
+// UPLO triangle only is kept, as in the reference, and the product applies every stored off-diagonal
+// leaf a second time, transposed (device.hip, "one-triangle storage").  See DESIGN.md "symmetry".
 #include <cmath>
 
 #include "hmatrix.hpp"
@@ -43,6 +44,9 @@ BlockRec make_block(const Ctx &c, int t, int s) {
     b.v_obase = 0;
     b.v_ostride = 0;
     b.status = 0;
+    b.z_obase = 0;
+    b.z_ostride = 0;
+    b.zfin = -1;
     return b;
 }
 
@@ -72,6 +76,10 @@ void split(const Ctx &c, int t, int s) {
 
 void visit(const Ctx &c, int t, int s) {
     if (c.T.size[t] == 0 || c.S.size[s] == 0) return;
+    if (c.P.store_one_triangle) { // skip what lies strictly in the triangle that is not stored
+        if (c.P.uplo == 'L' && c.S.offset[s] >= c.T.offset[t] + c.T.size[t]) return;
+        if (c.P.uplo == 'U' && c.T.offset[t] >= c.S.offset[s] + c.S.size[s]) return;
+    }
     if (admissible(c, t, s) && c.T.depth[t] >= c.P.min_target_depth && c.S.depth[s] >= c.P.min_source_depth) {
         c.adm.push_back(make_block(c, t, s));
         return;

@@ -191,6 +191,11 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     H.params.compress_ctx = params->compress_ctx;
     H.params.dense_blocks = params->dense_blocks;
     H.params.dense_blocks_ctx = params->dense_blocks_ctx;
+    if (params->store_one_triangle) {
+        const bool eligible = params->symmetry == 'S' && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition < 0 && source_partition < 0;
+        if (eligible) { H.params.store_one_triangle = 1; H.one_triangle = true; }
+        else log_message(LOG_WARNING, "store_one_triangle needs symmetry 'S' with UPLO 'L'/'U' on one cluster tree without partition restriction: storing both triangles");
+    }
     if (target_partition >= 0) {
         HM_CHECK(target_partition < (int)T->part_nodes.size(), "target_partition_number out of range");
         H.t_root = T->part_nodes[target_partition];
@@ -249,7 +254,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     const HMatrix &s = h->H;
     HMatrix &d = c->H;
     d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
-    d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size; d.local_numbering = s.local_numbering;
+    d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size; d.local_numbering = s.local_numbering; d.one_triangle = s.one_triangle;
     d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.blocks = s.blocks; d.r_elems = s.r_elems;
     d.build_seconds = s.build_seconds; d.n_batches = s.n_batches;
     c->tch = h->tch; c->sch = h->sch;
@@ -501,6 +506,8 @@ int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluste
     P.uplo = params->uplo;
     P.min_target_depth = params->minimal_target_depth;
     P.min_source_depth = params->minimal_source_depth;
+    if (params->store_one_triangle && params->symmetry == 'S' && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition_number < 0)
+        P.store_one_triangle = 1;
     int t_root = 0;
     if (target_partition_number >= 0) {
         HM_CHECK(target_partition_number < (int)T->part_nodes.size(), "target_partition_number out of range");

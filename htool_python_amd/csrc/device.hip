@@ -47,6 +47,11 @@ struct RealOps {
         acc.x = ::fma(v.x, w, acc.x);
         acc.y = ::fma(v.y, w, acc.y);
     }
+    // transposed use: the lane's two rows against their two coefficients
+    static __device__ __forceinline__ void tacc(T &acc, const double2 v, const double2 z) { acc = ::fma(v.x, z.x, ::fma(v.y, z.y, acc)); }
+    static __device__ __forceinline__ T shfl_xor(T v, int mask) { return __shfl_xor(v, mask); }
+    static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+    static __device__ __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
 };
 
 struct CplxOps {
@@ -59,6 +64,10 @@ struct CplxOps {
         acc.x = ::fma(v.x, w.x, ::fma(-v.y, w.y, acc.x));
         acc.y = ::fma(v.x, w.y, ::fma(v.y, w.x, acc.y));
     }
+    static __device__ __forceinline__ void tacc(T &acc, const double2 v, const double2 z) { fma(acc, v, z); } // no conjugation ('S')
+    static __device__ __forceinline__ T shfl_xor(T v, int mask) { return make_double2(__shfl_xor(v.x, mask), __shfl_xor(v.y, mask)); }
+    static __device__ __forceinline__ T add(T a, T b) { return make_double2(a.x + b.x, a.y + b.y); }
+    static __device__ __forceinline__ T sel(bool c, T a, T b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 };
 
 template <typename Ops>
@@ -275,6 +284,184 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// one-triangle storage of a symmetric operator ('S' with UPLO): every stored off-diagonal
+// leaf is used twice, as A_ts (y_t += A_ts x_s) and transposed (y_s += A_ts^T x_t), from ONE pass over its
+// panels.  Besides the plain product a lane also multiplies what it loaded with the x of its own rows; the
+// per-lane partials of 16 columns are summed across the 64 lanes by a transpose-reduce (17 cross-lane
+// exchanges for 16 sums instead of 96) in a fixed order, so the product stays bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+template <typename Ops, int HALF, int BIT>
+struct TransposeReduce {
+    // in: d[0 .. 2*HALF) per lane; out: d[0 .. HALF) with lanes whose bit BIT is set keeping the upper half
+    static __device__ __forceinline__ void step(typename Ops::T *d, int lane) {
+        const bool up = (lane & BIT) != 0;
+#pragma unroll
+        for (int u = 0; u < HALF; u++) {
+            const typename Ops::T keep = Ops::sel(up, d[u + HALF], d[u]);
+            const typename Ops::T send = Ops::sel(up, d[u], d[u + HALF]);
+            d[u] = Ops::add(keep, Ops::shfl_xor(send, BIT));
+        }
+    }
+};
+// 16 per-lane partials -> lane L ends with the 64-lane total of partial (L >> 2) & 15 in d[0]
+template <typename Ops>
+__device__ __forceinline__ void lane_transpose_reduce16(typename Ops::T *d, int lane) {
+    TransposeReduce<Ops, 8, 32>::step(d, lane);
+    TransposeReduce<Ops, 4, 16>::step(d, lane);
+    TransposeReduce<Ops, 2, 8>::step(d, lane);
+    TransposeReduce<Ops, 1, 4>::step(d, lane);
+    d[0] = Ops::add(d[0], Ops::shfl_xor(d[0], 2));
+    d[0] = Ops::add(d[0], Ops::shfl_xor(d[0], 1));
+}
+
+// phase B, fused with the transposed use of its columns: out (cluster numbering) = panels * W[cidx], and for every
+// column c with zidx[c] >= 0:  Wz[zidx[c]] = sum_i panel[c][i] * x[xoff + i]   (x = W[0 : n), cluster numbering)
+template <typename Ops>
+__global__ __launch_bounds__(256) void tile_gemv_wide_sym(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
+                                                          const typename Ops::T *W, typename Ops::T *Wz, typename Ops::T *__restrict__ out) {
+    typedef typename Ops::T T;
+    constexpr int CH = 16;
+    const GTile tl = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = lane * Ops::RPL;
+    const bool active = row0 < tl.nrows;
+    double2 xl = make_double2(0.0, 0.0); // x of the lane's rows
+    if (active) {
+        if constexpr (Ops::RPL == 2) {
+            const double *x = (const double *)W + tl.xoff + row0;
+            xl.x = x[0];
+            if (row0 + 1 < tl.nrows) xl.y = x[1];
+        } else {
+            xl = ((const double2 *)W)[tl.xoff + row0];
+        }
+    }
+    double2 acc = make_double2(0.0, 0.0);
+    for (int s = 0; s < tl.nseg; s++) {
+        const GSeg sg = segs[tl.seg_begin + s];
+        const T *base = (const T *)sg.panel + row0;
+        const long long ld = sg.ld_last;
+        const int ncols = sg.ncols;
+        for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
+            const int nc = min(CH, ncols - c0);
+            T coef = Ops::zero();
+            if (lane < nc) coef = W[sg.cidx[c0 + lane]];
+            const T *p = base + (long long)c0 * ld;
+            double2 v[CH];
+            if (nc == CH) {
+#pragma unroll
+                for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < CH; u++) v[u] = (active && u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+            }
+            T d[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                Ops::fma(acc, v[u], Ops::bcast(coef, u));
+                d[u] = Ops::zero();
+                Ops::tacc(d[u], v[u], xl);
+            }
+            lane_transpose_reduce16<Ops>(d, lane);
+            const int u = lane >> 2;
+            if ((lane & 3) == 0 && u < nc) {
+                const int zi = sg.zidx[c0 + u];
+                if (zi >= 0) Wz[zi] = d[0];
+            }
+        }
+    }
+    __shared__ double2 red[4][64];
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        double2 a = red[0][lane], b = red[1][lane], c = red[2][lane], e = red[3][lane];
+        double2 sum = make_double2(((a.x + b.x) + c.x) + e.x, ((a.y + b.y) + c.y) + e.y);
+        store_rows<Ops>(out, tl, row0, tl.nrows, sum);
+    }
+}
+
+// transposed use of the phase-A panels: ycl[out_begin + j] += sum_rows panel[row][j] * W[zidx[row]] for the
+// tl.nrows source positions j of the tile, over all segments (one per batch).  Wave w owns columns [w*CG, (w+1)*CG).
+template <typename Ops>
+__global__ __launch_bounds__(256) void tile_gemv_tall_transposed(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
+                                                                 const typename Ops::T *__restrict__ W, typename Ops::T *ycl) {
+    typedef typename Ops::T T;
+    constexpr int TM = 64 * Ops::RPL;
+    constexpr int CG = TM / 4; // columns per wave: 32 (real) / 16 (complex)
+    const GTile tl = tiles[blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = lane * Ops::RPL;
+    const int cs = tl.nrows; // source positions of the tile = columns of its panels
+    const int j0 = wave * CG;
+    if (j0 >= cs) return;
+    T acc[CG];
+#pragma unroll
+    for (int u = 0; u < CG; u++) acc[u] = Ops::zero();
+    for (int s = 0; s < tl.nseg; s++) {
+        const GSeg sg = segs[tl.seg_begin + s];
+        const int nr = sg.nrows_t;
+        const int nq = (nr + TM - 1) / TM;
+        for (int q = 0; q < nq; q++) {
+            const int rows_here = min(TM, nr - q * TM);
+            const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
+            const bool active = row0 < rows_here;
+            double2 z = make_double2(0.0, 0.0); // coefficients of the lane's rows
+            bool second = true;
+            if (active) {
+                const int *zi = sg.zidx + q * TM + row0;
+                if constexpr (Ops::RPL == 2) {
+                    z.x = ((const double *)W)[zi[0]];
+                    second = row0 + 1 < rows_here;
+                    if (second) z.y = ((const double *)W)[zi[1]];
+                } else {
+                    z = ((const double2 *)W)[zi[0]];
+                }
+            }
+            const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0 + (long long)j0 * ld;
+#pragma unroll
+            for (int cc = 0; cc < CG; cc += 16) {
+                double2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = (active && j0 + cc + u < cs) ? ldnt16(base + (long long)(cc + u) * ld) : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (Ops::RPL == 2 && !second) v[u].y = 0.0; // the padding row of an odd last chunk is never written
+                    Ops::tacc(acc[cc + u], v[u], z);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < CG; cc += 16) {
+        lane_transpose_reduce16<Ops>(acc + cc, lane);
+        const int j = j0 + cc + (lane >> 2);
+        if ((lane & 3) == 0 && j < cs) {
+            T *o = ycl + tl.out_begin + j;
+            *o = Ops::add(*o, acc[cc]);
+        }
+    }
+}
+
+// last pass of the one-triangle product: y[map(i)] = ycl[i] + sum of the transposed dense-leaf results that land
+// on row i (W[woff + i - tile offset], entries in table order); one workgroup per row tile
+template <typename T>
+__global__ __launch_bounds__(128) void finish_sym_kernel(const T *__restrict__ ycl, const T *__restrict__ W, const int *__restrict__ zd_ptr,
+                                                         const long long *__restrict__ zd_woff, const int *__restrict__ tile_rows,
+                                                         const int *__restrict__ perm, T *__restrict__ y) {
+    const int r = blockIdx.x, i = threadIdx.x;
+    const int off = tile_rows[2 * r], size = tile_rows[2 * r + 1];
+    if (i >= size) return;
+    T a = ycl[off + i];
+    for (int e = zd_ptr[r]; e < zd_ptr[r + 1]; e++) {
+        const T v = W[zd_woff[e] + i];
+        if constexpr (sizeof(T) == 8) a = a + v;
+        else { a.x += v.x; a.y += v.y; }
+    }
+    y[perm ? (long long)perm[off + i] : (long long)(off + i)] = a;
+}
+
 // W[r][i] = X[r][perm[i]] for the nr right-hand sides of one sweep
 template <typename T>
 __global__ void gather_x_kernel(const T *__restrict__ x, long long x_stride, const int *__restrict__ perm, T *__restrict__ W, long long w_stride, int n, int nr) {
@@ -355,6 +542,7 @@ struct PackArgs {
     const long long *tile_pbase, *tile_ibase;
     void *panel;
     int *index;                // cidxB / oidxA
+    int *index2;               // one-triangle storage: zidxB / tidxA (null otherwise)
     const void *arena;
     int vec_rows, tile_max;
     int col_off;               // first source position covered by the H-matrix (coefficient indices are relative to it)
@@ -387,7 +575,11 @@ __global__ __launch_bounds__(256) void pack_u_kernel(PackArgs a) {
         else if (b.rank < 0 && a.eval_dense) gen_eval(a.gen, toff + i, b.s_off + k, v);
         else v = src[(long long)k * b.m + i];
         dst[(long long)k * ld + i] = v;
-        if (i == 0) cidx[k] = b.rank >= 0 ? (int)(b.tpos + k) : b.s_off - a.col_off + k;
+        if (i == 0) {
+            cidx[k] = b.rank >= 0 ? (int)(b.tpos + k) : b.s_off - a.col_off + k;
+            // transposed use: partial (or final) slot of this column for this row tile; diagonal leaves are applied once
+            if (a.index2) a.index2[a.tile_ibase[r] + b.ucol + k] = b.t_off == b.s_off ? -1 : (int)(b.z_obase + (long long)(r - b.z_tile0) * b.z_ostride + k);
+        }
     }
 }
 
@@ -414,7 +606,10 @@ __global__ __launch_bounds__(256) void pack_v_kernel(PackArgs a) {
         const long long di = (long long)q * cs * TM + (long long)j * ld + rl;
         if (REVERSE) { src[(long long)k * b.n + j] = dst[di]; continue; }
         dst[di] = src[(long long)k * b.n + j];
-        if (j == 0) oidx[k] = (int)(b.v_obase + (long long)p * b.v_ostride + k);
+        if (j == 0) {
+            oidx[k] = (int)(b.v_obase + (long long)p * b.v_ostride + k);
+            if (a.index2) a.index2[a.tile_ibase[c] + b.vcol + k] = (int)(b.zfin + k); // coefficient of the row in the transposed use
+        }
     }
 }
 
@@ -519,6 +714,8 @@ static DevBlock to_dev(const BlockRec &b, const HMatrix &H) {
     d.ucol = b.ucol; d.vcol = b.vcol; d.v_ostride = b.v_ostride;
     d.v_tile0 = H.ctiles.node_tile_begin[b.s_node];
     d.status = b.status; d.pad_ = 0;
+    d.z_obase = b.z_obase; d.zfin = b.zfin; d.z_ostride = b.z_ostride;
+    d.z_tile0 = H.rtiles.node_tile_begin[b.t_node];
     return d;
 }
 
@@ -581,6 +778,11 @@ struct DeviceBuilder {
         B.cidxB = (int *)owned.alloc(std::max<int64_t>(L.cidxB_elems, 1) * sizeof(int));
         B.oidxA = (int *)owned.alloc(std::max<int64_t>(L.oidxA_elems, 1) * sizeof(int));
         B.bytes = szB + szA + (L.cidxB_elems + L.oidxA_elems) * sizeof(int);
+        if (H.one_triangle) {
+            B.zidxB = (int *)owned.alloc(std::max<int64_t>(L.cidxB_elems, 1) * sizeof(int));
+            B.tidxA = (int *)owned.alloc(std::max<int64_t>(L.oidxA_elems, 1) * sizeof(int));
+            B.bytes += (L.cidxB_elems + L.oidxA_elems) * sizeof(int);
+        }
         std::vector<DevBlock> hb(batch_blocks.size());
         for (size_t q = 0; q < batch_blocks.size(); q++) hb[q] = to_dev(H.blocks[batch_blocks[q]], H);
         TempPool tmp;
@@ -595,11 +797,11 @@ struct DeviceBuilder {
         a.eval_dense = eval_dense ? 1 : 0; a.gen = gen;
         // U / dense side
         a.item_block = d_ub; a.item_tile = d_ut; a.tile_off = d_rt_off; a.tile_size = d_rt_size; a.tile_n = d_bn;
-        a.tile_pbase = d_bp; a.tile_ibase = d_bc; a.panel = B.panelB; a.index = B.cidxB;
+        a.tile_pbase = d_bp; a.tile_ibase = d_bc; a.panel = B.panelB; a.index = B.cidxB; a.index2 = B.zidxB;
         if (!L.u_item_block.empty()) hipLaunchKernelGGL((pack_u_kernel<T, false>), dim3((unsigned)L.u_item_block.size()), dim3(256), 0, D->stream, a);
         // V side
         a.item_block = d_vb; a.item_tile = d_vt; a.tile_off = d_ct_off; a.tile_size = d_ct_size; a.tile_n = d_an;
-        a.tile_pbase = d_ap; a.tile_ibase = d_ao; a.panel = B.panelA; a.index = B.oidxA;
+        a.tile_pbase = d_ap; a.tile_ibase = d_ao; a.panel = B.panelA; a.index = B.oidxA; a.index2 = B.tidxA;
         if (!L.v_item_block.empty()) hipLaunchKernelGGL((pack_v_kernel<T, false>), dim3((unsigned)L.v_item_block.size()), dim3(256), 0, D->stream, a);
         HIP_OK(hipGetLastError());
         double tl2 = wall_seconds();
@@ -609,10 +811,13 @@ struct DeviceBuilder {
         bt.b_ncols.swap(L.b_ncols); bt.a_nrows.swap(L.a_nrows);
         bt.b_pbase.swap(L.b_pbase); bt.b_cbase.swap(L.b_cbase); bt.a_pbase.swap(L.a_pbase); bt.a_obase.swap(L.a_obase);
         bt.reduces.swap(L.reduces);
+        bt.z_reduces.swap(L.z_reduces); bt.zd_tile.swap(L.zd_tile); bt.zd_woff.swap(L.zd_woff);
         owned.ptrs.clear(); // success: ownership moves to the device H-matrix
         if (replace_index >= 0) {
             DevBatch &old = D->batches[replace_index];
             (void)hipFree(old.panelB); (void)hipFree(old.panelA); (void)hipFree(old.cidxB); (void)hipFree(old.oidxA);
+            if (old.zidxB) (void)hipFree(old.zidxB);
+            if (old.tidxA) (void)hipFree(old.tidxA);
             old = B;
             D->tabs[replace_index] = std::move(bt);
         } else {
@@ -656,8 +861,11 @@ struct DeviceBuilder {
     // drop W and the product tables (they are rebuilt by assemble())
     void free_product_tables() {
         for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->tilesB_split,
-                        (void *)D->perm_s, (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, D->ypart})
+                        (void *)D->perm_s, (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, D->ypart,
+                        (void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl})
             if (p) (void)hipFree(p);
+        D->tilesAT = D->tilesZ = nullptr; D->zd_ptr = D->zd_rows = nullptr; D->zd_woff = nullptr; D->ycl = nullptr;
+        D->nAT = D->nZ = D->n_zd_tiles = 0;
         D->segs = nullptr; D->tilesB_user = D->tilesB_cluster = D->tilesA = D->tilesA2 = D->tilesB_split = nullptr;
         D->perm_s = D->perm_t = D->iota = D->ones_idx = nullptr;
         D->W = D->x_tmp = D->y_tmp = D->ypart = nullptr;
@@ -689,6 +897,8 @@ struct DeviceBuilder {
         D->iota = upload(io, &D->table_bytes);
         int maxP = 1;
         for (auto &bt : tabs) for (auto &r : bt.reduces) maxP = std::max(maxP, r.ncols);
+        for (auto &bt : tabs) for (auto &r : bt.z_reduces) maxP = std::max(maxP, r.ncols);
+        D->one_triangle = H.one_triangle;
         std::vector<int> ones(maxP, Ns);
         D->ones_idx = upload(ones, &D->table_bytes);
         HIP_OK(hipMalloc(&D->x_tmp, (size_t)std::max(Ns, 1) * sizeof(T)));
@@ -711,13 +921,15 @@ struct DeviceBuilder {
                 GSeg s;
                 s.panel = (const char *)D->batches[b].panelB + (size_t)tabs[b].b_pbase[r] * sizeof(T);
                 s.cidx = D->batches[b].cidxB + tabs[b].b_cbase[r];
-                s.ncols = nc; s.ld_full = ld; s.ld_last = ld; s.pad_ = 0; s.chunk_stride = 0;
+                s.ncols = nc; s.ld_full = ld; s.ld_last = ld; s.nrows_t = 0; s.chunk_stride = 0;
+                if (H.one_triangle) s.zidx = D->batches[b].zidxB + tabs[b].b_cbase[r];
                 segs.push_back(s);
                 t.nseg++;
                 work += (double)nc * ld;
             }
             t.omap = D->perm_t + H.rtiles.off[r];
             t.out_begin = 0;
+            t.xoff = H.rtiles.off[r];
             tB.push_back(t);
             GTile tc = t;
             tc.omap = nullptr;
@@ -738,7 +950,7 @@ struct DeviceBuilder {
                 GSeg s;
                 s.panel = (const char *)D->batches[b].panelA + (size_t)tabs[b].a_pbase[c] * sizeof(T);
                 s.cidx = D->iota + (H.ctiles.off[c] - H.col_off);
-                s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.pad_ = 0;
+                s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.nrows_t = 0;
                 s.chunk_stride = (long long)H.ctiles.size[c] * TM;
                 // cut tall tiles into pieces of at most qmax row chunks (independent outputs, no reduction)
                 for (int q0 = 0; q0 < nq; q0 += qmax) {
@@ -759,7 +971,7 @@ struct DeviceBuilder {
             for (auto &r : tabs[b].reduces) {
                 GSeg s;
                 s.panel = (const char *)D->W + (size_t)r.w_panel * sizeof(T);
-                s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.pad_ = 0; s.chunk_stride = TM;
+                s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.nrows_t = 0; s.chunk_stride = TM;
                 GTile t;
                 t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = r.nrows; t.omap = nullptr; t.out_begin = r.out_base;
                 segs.push_back(s);
@@ -779,6 +991,7 @@ struct DeviceBuilder {
         std::vector<GTile> tBs;
         std::vector<double> wBs;
         D->splitB = std::max(1, std::min(8, (target_items + std::max(nrt, 1) - 1) / std::max(nrt, 1)));
+        if (H.one_triangle) D->splitB = 1; // the fused sweep writes whole rows of the cluster-numbered accumulator
         if (D->splitB > 1) {
             const int S = D->splitB;
             D->ypart_stride = ((long long)H.row_size + 1) / 2 * 2;
@@ -821,7 +1034,11 @@ struct DeviceBuilder {
         }
         sort_heavy(tB, wB, &tBc);
         // classes of the wide kernel (columns per wave instruction F = 1, 2, 4), heavy-first inside each class
-        auto tile_class = [&](const GTile &t) { int lanes = (t.nrows + vec_rows - 1) / vec_rows; return lanes <= 16 ? 2 : (lanes <= 32 ? 1 : 0); };
+        auto tile_class = [&](const GTile &t) {
+            if (H.one_triangle) return 0; // one kernel (tile_gemv_wide_sym) for every row tile
+            int lanes = (t.nrows + vec_rows - 1) / vec_rows;
+            return lanes <= 16 ? 2 : (lanes <= 32 ? 1 : 0);
+        };
         auto by_class = [&](std::vector<GTile> &t, std::vector<GTile> *twin, int *cnt) {
             std::vector<GTile> o, o2;
             for (int c = 0; c < 3; c++) {
@@ -835,6 +1052,63 @@ struct DeviceBuilder {
         by_class(tBs, nullptr, D->cntBs);
         sort_heavy(tA, wA, nullptr);
         sort_heavy(tA2, wA2, nullptr);
+        if (H.one_triangle) {
+            // transposed use of the phase-A panels: one tile per source tile, one segment per batch (a tile owns its rows of y)
+            std::vector<GTile> tAT, tZ;
+            std::vector<double> wAT, wZ;
+            for (int c = 0; c < nct; c++) {
+                GTile t;
+                t.seg_begin = (long long)segs.size(); t.nseg = 0;
+                t.nrows = H.ctiles.size[c];
+                t.omap = nullptr; t.out_begin = H.ctiles.off[c];
+                double work = 0;
+                for (size_t b = 0; b < tabs.size(); b++) {
+                    const int nr = tabs[b].a_nrows[c];
+                    if (nr == 0) continue;
+                    const int nq = (nr + TM - 1) / TM, rem = nr - (nq - 1) * TM;
+                    GSeg s;
+                    s.panel = (const char *)D->batches[b].panelA + (size_t)tabs[b].a_pbase[c] * sizeof(T);
+                    s.cidx = D->iota;
+                    s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows;
+                    s.nrows_t = nr;
+                    s.chunk_stride = (long long)H.ctiles.size[c] * TM;
+                    s.zidx = D->batches[b].tidxA + tabs[b].a_obase[c];
+                    segs.push_back(s);
+                    t.nseg++;
+                    work += (double)nr * s.ncols;
+                }
+                if (t.nseg) { tAT.push_back(t); wAT.push_back(work); }
+            }
+            for (size_t b = 0; b < tabs.size(); b++)
+                for (auto &r : tabs[b].z_reduces) {
+                    GSeg s;
+                    s.panel = (const char *)D->W + (size_t)r.w_panel * sizeof(T);
+                    s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.nrows_t = 0; s.chunk_stride = TM;
+                    GTile t;
+                    t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = r.nrows; t.omap = nullptr; t.out_begin = r.out_base;
+                    segs.push_back(s);
+                    tZ.push_back(t);
+                    wZ.push_back((double)r.nrows * r.ncols);
+                }
+            sort_heavy(tAT, wAT, nullptr);
+            sort_heavy(tZ, wZ, nullptr);
+            D->tilesAT = upload(tAT, &D->table_bytes);
+            D->tilesZ = upload(tZ, &D->table_bytes);
+            D->nAT = (int)tAT.size(); D->nZ = (int)tZ.size();
+            // transposed dense leaves: per row tile of y the W offsets to add (batch order, then leaf order)
+            std::vector<int> zptr(nrt + 1, 0), rows(2 * (size_t)nrt);
+            for (auto &bt : tabs) for (int c : bt.zd_tile) zptr[c + 1]++;
+            for (int r = 0; r < nrt; r++) { zptr[r + 1] += zptr[r]; rows[2 * r] = H.rtiles.off[r]; rows[2 * r + 1] = H.rtiles.size[r]; }
+            std::vector<long long> zw((size_t)zptr[nrt]);
+            std::vector<int> fill(zptr.begin(), zptr.end() - 1);
+            for (auto &bt : tabs) for (size_t e = 0; e < bt.zd_tile.size(); e++) zw[fill[bt.zd_tile[e]]++] = bt.zd_woff[e];
+            D->zd_ptr = upload(zptr, &D->table_bytes);
+            D->zd_woff = upload(zw, &D->table_bytes);
+            D->zd_rows = upload(rows, &D->table_bytes);
+            D->n_zd_tiles = nrt;
+            HIP_OK(hipMalloc(&D->ycl, (size_t)std::max(Tt.n_points, 1) * sizeof(T)));
+            D->table_bytes += (size_t)Tt.n_points * sizeof(T);
+        }
         D->segs = upload(segs, &D->table_bytes);
         D->tilesB_user = upload(tB, &D->table_bytes);
         D->tilesB_cluster = upload(tBc, &D->table_bytes);
@@ -887,7 +1161,20 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
         t += cnt[1];
         if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 4>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
     };
-    if (D->splitB > 1 && D->nB_split) {
+    if (D->one_triangle) {
+        // fused sweep: y (cluster numbering) and the transposed dot products of every column, then the transposed
+        // use of the V panels, then the transposed dense results and the scatter to the caller's numbering
+        if constexpr (NR == 1) {
+            T *ycl = (T *)D->ycl;
+            if (D->nB) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const T *)W, W, ycl);
+            if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, 1>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, 0LL);
+            if (D->nAT) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl);
+            if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym_kernel<T>, dim3(D->n_zd_tiles), dim3(128), 0, st, (const T *)ycl, (const T *)W, D->zd_ptr, D->zd_woff, D->zd_rows,
+                                                  out_user ? D->perm_t : (const int *)nullptr, (T *)y_dev);
+        } else {
+            throw Error("one-triangle storage: products are swept one right-hand side at a time");
+        }
+    } else if (D->splitB > 1 && D->nB_split) {
         const long long ps = (long long)D->splitB * D->ypart_stride;
         launch_wide(D->tilesB_split, D->cntBs, (T *)D->ypart, ps);
         hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
@@ -939,6 +1226,7 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
         const int left = mu - done;
         const T *x = (const T *)X + (long long)done * x_stride;
         T *y = (T *)Y + (long long)done * y_stride;
+        if (D->one_triangle) { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; continue; }
         if (left >= 8) { launch_sweep<Ops, 8>(D, x, x_stride, y, y_stride, numbering, st); done += 8; }
         else if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
         else if (left >= 2) { launch_sweep<Ops, 2>(D, x, x_stride, y, y_stride, numbering, st); done += 2; }
@@ -952,7 +1240,7 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
-    const int need = mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1;
+    const int need = D->one_triangle ? 1 : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
     if (need > D->rhs_cap) {
         HIP_OK(hipStreamSynchronize(st));
         if (D->is_complex) ensure_rhs_capacity<double2>(D, need);
@@ -1049,7 +1337,13 @@ int64_t device_resident_bytes(const HMatrix &H) {
 void device_free(DeviceHMatrix *D) {
     if (!D) return;
     (void)hipSetDevice(D->device);
-    for (auto &B : D->batches) { (void)hipFree(B.panelB); (void)hipFree(B.panelA); (void)hipFree(B.cidxB); (void)hipFree(B.oidxA); }
+    for (auto &B : D->batches) {
+        (void)hipFree(B.panelB); (void)hipFree(B.panelA); (void)hipFree(B.cidxB); (void)hipFree(B.oidxA);
+        if (B.zidxB) (void)hipFree(B.zidxB);
+        if (B.tidxA) (void)hipFree(B.tidxA);
+    }
+    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl})
+        if (p) (void)hipFree(p);
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
                     (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord, (void *)D->tilesB_split, D->ypart})
         if (p) (void)hipFree(p);
@@ -1094,7 +1388,13 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
         D->batches[b].panelA = dup_alloc(S->batches[b].panelA);
         D->batches[b].cidxB = (int *)dup_alloc(S->batches[b].cidxB);
         D->batches[b].oidxA = (int *)dup_alloc(S->batches[b].oidxA);
+        D->batches[b].zidxB = (int *)dup_alloc(S->batches[b].zidxB);
+        D->batches[b].tidxA = (int *)dup_alloc(S->batches[b].tidxA);
     }
+    D->zd_ptr = (int *)dup_alloc(S->zd_ptr);
+    D->zd_woff = (long long *)dup_alloc(S->zd_woff);
+    D->zd_rows = (int *)dup_alloc(S->zd_rows);
+    D->ycl = dup_alloc(S->ycl);
     D->W = dup_alloc(S->W);
     D->perm_s = (int *)dup_alloc(S->perm_s);
     D->perm_t = (int *)dup_alloc(S->perm_t);
@@ -1126,9 +1426,11 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     fix_tiles(S->tilesA, S->nA, &D->tilesA);
     fix_tiles(S->tilesA2, S->nA2, &D->tilesA2);
     fix_tiles(S->tilesB_split, S->nB_split, &D->tilesB_split);
+    fix_tiles(S->tilesAT, S->nAT, &D->tilesAT);
+    fix_tiles(S->tilesZ, S->nZ, &D->tilesZ);
     if (S->ypart) D->ypart = dup_alloc(S->ypart);
     segs.resize((size_t)nseg_used);
-    for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); }
+    for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); s.zidx = (const int *)reloc(s.zidx); }
     D->segs = upload(segs);
     (void)es;
 }

@@ -22,8 +22,10 @@ struct GSeg {
     int ncols;
     int ld_full;           // leading dimension of full row chunks
     int ld_last;           // leading dimension of the last (or only) row chunk
-    int pad_;
+    int nrows_t = 0;       // rows of the panel (transposed use of a tall panel only)
     long long chunk_stride; // elements between consecutive row chunks
+    const int *zidx = nullptr;      // one-triangle storage: per column, where its transposed dot product goes in W (-1: nowhere);
+                            // for the transposed use of a tall panel: per row, the index in W of its coefficient
 };
 
 struct GTile {
@@ -32,11 +34,14 @@ struct GTile {
     int nrows;
     const int *omap;       // output index of row i is omap[i] when non-null ...
     long long out_begin;   // ... and out_begin + i otherwise
+    int xoff = 0;          // cluster position of the tile's first row (one-triangle storage: x of the tile = W[xoff + i])
+    int pad_ = 0;
 };
 
 struct DevBatch {
     void *panelB = nullptr, *panelA = nullptr;
     int *cidxB = nullptr, *oidxA = nullptr;
+    int *zidxB = nullptr, *tidxA = nullptr; // one-triangle storage only (same shapes as cidxB / oidxA)
     size_t bytes = 0;
 };
 
@@ -45,6 +50,9 @@ struct BatchTables {
     std::vector<int> b_ncols, a_nrows;
     std::vector<int64_t> b_pbase, b_cbase, a_pbase, a_obase;
     std::vector<BatchLayout::Reduce> reduces;
+    std::vector<BatchLayout::Reduce> z_reduces;
+    std::vector<int> zd_tile;
+    std::vector<int64_t> zd_woff;
 };
 
 struct DeviceHMatrix {
@@ -59,6 +67,15 @@ struct DeviceHMatrix {
     // small operators: every row tile is cut in splitB column slices (more, smaller workgroups); the slices
     // write partial sums to ypart[slice][row] and reduce_y_kernel adds them in slice order
     int splitB = 1, nB_split = 0;
+    // one-triangle storage of a symmetric operator: extra tables and a cluster-numbered accumulator for y
+    bool one_triangle = false;
+    GTile *tilesAT = nullptr, *tilesZ = nullptr; // transposed use of the tall panels; sums of the transposed partials
+    int nAT = 0, nZ = 0;
+    int *zd_ptr = nullptr;          // per row tile: range of zd_woff entries to add
+    long long *zd_woff = nullptr;
+    int *zd_rows = nullptr;         // per row tile: offset and size (2 ints)
+    int n_zd_tiles = 0;
+    void *ycl = nullptr;
     int cntB[3] = {0, 0, 0}, cntBs[3] = {0, 0, 0}; // tiles per class of the wide kernel (F = 1, 2, 4 columns per wave instruction)
     GTile *tilesB_split = nullptr;
     void *ypart = nullptr;
@@ -91,6 +108,8 @@ struct DevBlock {
     int ucol, vcol;
     int v_ostride, v_tile0;
     int status, pad_;
+    long long z_obase, zfin; // one-triangle storage (see BlockRec)
+    int z_ostride, z_tile0;
 };
 
 } // namespace hm

@@ -36,6 +36,10 @@ struct BlockRec {
     int64_t v_obase;      // phase-A output index of (k=0, first source tile)
     int v_ostride;        // phase-A output stride between consecutive source tiles (0: single tile)
     int status;           // device ACA status (0 ok, 1 not compressible, 2 capacity exceeded)
+    // one-triangle storage only: where the transposed use of the leaf's phase-B columns is written / read
+    int64_t z_obase = 0;  // output index of (column 0, first row tile of the target node) in W
+    int z_ostride = 0;    // stride between consecutive row tiles (0: the target node is a single tile)
+    int64_t zfin = -1;    // index in W of the reduced transposed coefficients of column 0 (t'_b[0], or the dense leaf's A^T x); -1: none
 };
 
 struct TileSet {
@@ -65,6 +69,11 @@ struct BatchLayout {
     // phase A2 tiles: (partial panel offset in W, ld, rows, cols, output base in W)
     struct Reduce { int64_t w_panel; int ld; int nrows; int ncols; int64_t out_base; };
     std::vector<Reduce> reduces;
+    // one-triangle storage: sums of the per-row-tile transposed partials (run after phase B), and for every
+    // stored off-diagonal dense leaf the row tiles of y that receive its transposed contribution
+    std::vector<Reduce> z_reduces;
+    std::vector<int> zd_tile;        // row tile (of y) receiving a dense leaf's A^T x ...
+    std::vector<int64_t> zd_woff;    // ... which starts at this index of W
     // pack work items (block index into `blocks`, tile id)
     std::vector<int> u_item_block, u_item_tile, v_item_block, v_item_tile;
 };
@@ -75,6 +84,7 @@ struct BuildParams {
     double epsilon = 1e-3, eta = 10;
     char symmetry = 'N', uplo = 'N';
     int reqrank = -1, min_target_depth = 0, min_source_depth = 0, block_tree_consistency = 1;
+    int store_one_triangle = 0; // 'S'/'H' on one cluster tree: keep the UPLO triangle only and apply stored leaves transposed too
     int (*compress)(void *, int, int, const int *, const int *, double, const void **, const void **, int *) = nullptr;
     void *compress_ctx = nullptr;
     void (*dense_blocks)(void *, int, const int *, const int *, const int *, const int *, void **) = nullptr;
@@ -101,6 +111,7 @@ struct HMatrix {
     int s_root = 0;                 // source node (root, or a partition for block-diagonal / local operators)
     int col_off = 0, col_size = 0;  // columns covered, cluster numbering
     bool local_numbering = false;   // built as a local block: host products use cluster order on both sides
+    bool one_triangle = false;      // symmetric operator stored as its UPLO triangle (off-diagonal leaves are applied twice)
     bool is_complex = false;
     BuildParams params;
     int tile_max = 128;

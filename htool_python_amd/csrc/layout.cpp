@@ -113,6 +113,43 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
         else { b.v_obase = b.tpos; b.v_ostride = 0; }
     }
 
+    // ---- one-triangle storage: slots for the transposed use of every phase-B column.  Per target node the columns
+    // (low-rank first, then dense, in ucol order) get a contiguous block of final slots; nodes spanning several row
+    // tiles also get a [tile][column] panel of partials that is summed after phase B (same scheme as the source side).
+    if (H.one_triangle) {
+        std::vector<int64_t> zf(nt, -1), zp(nt, -1);
+        std::vector<int> zld(nt, 0);
+        int64_t cur2 = H.r_elems;
+        for (int id = 0; id < nt; id++) {
+            const int K = Klr[id] + Kdn[id];
+            if (K == 0) continue;
+            zf[id] = cur2;
+            cur2 += K;
+            const int P = H.rtiles.node_tile_end[id] - H.rtiles.node_tile_begin[id];
+            if (P > 1) {
+                cur2 = (cur2 + 1) / 2 * 2;
+                zld[id] = round_up(K, vec_rows);
+                zp[id] = cur2;
+                cur2 += (int64_t)P * zld[id];
+                L.z_reduces.push_back({r_start + zp[id], zld[id], K, P, r_start + zf[id]});
+            }
+        }
+        H.r_elems = cur2;
+        for (int64_t bi : batch_blocks) {
+            BlockRec &b = H.blocks[bi];
+            const int local = b.ucol - tbase[b.t_node]; // column of the leaf inside its node's block
+            b.zfin = r_start + zf[b.t_node] + local;
+            if (zp[b.t_node] >= 0) { b.z_obase = r_start + zp[b.t_node] + local; b.z_ostride = zld[b.t_node]; }
+            else { b.z_obase = b.zfin; b.z_ostride = 0; }
+            if (b.t_off == b.s_off) continue; // diagonal leaf: applied once
+            if (b.rank < 0) // dense: A^T x goes to the y rows of the leaf's source cluster, tile by tile
+                for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) {
+                    L.zd_tile.push_back(c);
+                    L.zd_woff.push_back(b.zfin + (H.ctiles.off[c] - b.s_off));
+                }
+        }
+    }
+
     // ---- pack work items
     for (size_t q = 0; q < batch_blocks.size(); q++) {
         const BlockRec &b = H.blocks[batch_blocks[q]];

@@ -1,0 +1,155 @@
+"""GPU parity tests of one-triangle symmetric storage (`HMatrixTreeBuilder.set_symmetric_storage(True)`):
+symmetry 'S' keeps the UPLO triangle only, as the reference does, and the product uses every
+stored off-diagonal leaf twice in one fused sweep.  Checked against the CPU restatement, which stores the same
+triangle, and against the exact dense kernel.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sym_build(pts, kind, p0, eps, eta, leaf, uplo, complex_=False, one_triangle=True, native=True):
+    import Htool
+    from tests.helpers import cluster_of, NumpyGenerator
+
+    cl = cluster_of(pts, leaf)
+    name = {0: "inv_delta", 1: "laplace", 2: "helmholtz"}[kind]
+    if complex_:
+        gen = Htool.ComplexNativeGenerator(name, pts, pts, p0)
+        builder = Htool.ComplexHMatrixTreeBuilder(eps, eta, "S", uplo)
+    else:
+        gen = Htool.NativeGenerator(name, pts, pts, p0) if native else NumpyGenerator(pts, pts, kind, p0)
+        builder = Htool.HMatrixTreeBuilder(eps, eta, "S", uplo)
+    builder.set_symmetric_storage(one_triangle)
+    return builder.build(gen, cl, cl), cl, gen
+
+
+@pytest.mark.parametrize("n,leaf,eta,eps,kind,p0,uplo", [
+    (3000, 10, 10.0, 1e-3, 0, 0.1, "L"),
+    (3000, 10, 10.0, 1e-3, 0, 0.1, "U"),
+    (9000, 100, 10.0, 1e-4, 1, 0.0, "L"),
+    (7001, 300, 3.0, 1e-5, 1, 0.0, "U"),   # leaves above the tile size: clusters cut into several tiles
+    (5000, 33, 100.0, 1e-3, 1, 0.0, "L"),
+])
+def test_one_triangle_matches_cpu_storage_and_product(built, oracle, n, leaf, eta, eps, kind, p0, uplo):
+    O = oracle
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H, cl, _ = _sym_build(pts, kind, p0, eps, eta, leaf, uplo)
+    oc = O.Cluster(pts, max_leaf=leaf)
+    OH = O.HMatrix(oc, oc, kind, p0, eps=eps, eta=eta, symmetry="S", uplo=uplo)
+    mine = {tuple(l[:4]): int(l[4]) for l in np.asarray(H.leaves())}
+    theirs = {tuple(l[:4]): int(l[4]) for l in OH.leaves}
+    assert set(mine) == set(theirs)          # the same triangle is stored, leaf for leaf
+    for (to, m, so, nn) in mine:              # nothing strictly in the other triangle
+        assert (so < to + m) if uplo == "L" else (to < so + nn)
+    diff = np.array([mine[k] - theirs[k] for k in mine])
+    assert np.mean(diff != 0) < 0.01 and np.abs(diff).max() <= 1
+    np.random.seed(1)
+    x = np.random.rand(n)
+    y, y_cpu = H * x, OH.matvec(x)
+    y_exact = O.dense_matvec(kind, pts, pts, x, p0)
+    e_gpu = np.linalg.norm(y - y_exact) / np.linalg.norm(y_exact)
+    e_cpu = np.linalg.norm(y_cpu - y_exact) / np.linalg.norm(y_exact)
+    assert e_gpu < eps
+    assert e_gpu < 1.5 * e_cpu + 1e-14
+    assert np.linalg.norm(y - y_cpu) / np.linalg.norm(y_cpu) < 2 * eps
+    # bitwise reproducible (fixed summation order, no atomics)
+    assert np.array_equal(H * x, y)
+    # several right-hand sides go through the same sweep one at a time
+    X = np.asfortranarray(np.random.rand(n, 3))
+    Y = H @ X
+    for j in range(3):
+        assert np.array_equal(Y[:, j], H * np.ascontiguousarray(X[:, j]))
+
+
+def test_one_triangle_equals_two_triangle_operator(built, oracle):
+    """Both storages hold the same leaves on the stored triangle (bitwise) and give the same product to rounding."""
+    O = oracle
+    n, leaf, eps, eta = 6000, 50, 1e-4, 10.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H1, cl, _ = _sym_build(pts, 1, 0.0, eps, eta, leaf, "L", one_triangle=True)
+    H2, _, _ = _sym_build(pts, 1, 0.0, eps, eta, leaf, "L", one_triangle=False)
+    L1, L2 = np.asarray(H1.leaves()), np.asarray(H2.leaves())
+    full = {tuple(l[:4]): i for i, l in enumerate(L2)}
+    assert len(L1) < len(L2)
+    rng = np.random.RandomState(0)
+    for i in rng.choice(len(L1), 40, replace=False):
+        j = full[tuple(L1[i, :4])]
+        assert L1[i, 4] == L2[j, 4]
+        A1, B1 = H1.leaf_panels(int(i))
+        A2, B2 = H2.leaf_panels(int(j))
+        assert np.array_equal(np.asarray(A1), np.asarray(A2))
+        if L1[i, 4] > 0:
+            assert np.array_equal(np.asarray(B1), np.asarray(B2))
+    x = np.random.rand(n)
+    y1, y2 = H1 * x, H2 * x
+    assert np.linalg.norm(y1 - y2) / np.linalg.norm(y2) < 1e-13
+    # roughly half the bytes
+    s1, s2 = H1.stats(), H2.stats()
+    e1, e2 = s1["dense_elements"] + s1["low_rank_elements"], s2["dense_elements"] + s2["low_rank_elements"]
+    assert 0.45 < e1 / e2 < 0.62
+    assert s1["hbm_bytes"] < 0.7 * s2["hbm_bytes"]
+    D = H1.to_dense_in_user_numbering()
+    assert np.abs(D - D.T).max() <= 1e-13 * np.abs(D).max()
+    K = O.kernel_block(1, pts, pts, 0.0)
+    assert np.linalg.norm(D - K) / np.linalg.norm(K) < eps
+
+
+def test_one_triangle_complex_symmetric(built, oracle):
+    O = oracle
+    n, leaf, eps, eta, kappa = 4000, 40, 1e-4, 10.0, 5.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H, cl, _ = _sym_build(pts, 2, kappa, eps, eta, leaf, "L", complex_=True)
+    x = np.random.rand(n) + 1j * np.random.rand(n)
+    y = H * x
+    y_exact = O.dense_matvec(2, pts, pts, x, kappa)
+    assert np.linalg.norm(y - y_exact) / np.linalg.norm(y_exact) < eps
+    oc = O.Cluster(pts, max_leaf=leaf)
+    OH = O.HMatrix(oc, oc, 2, kappa, is_complex=True, eps=eps, eta=eta, symmetry="S", uplo="L")
+    assert {tuple(l[:4]) for l in np.asarray(H.leaves())} == {tuple(l[:4]) for l in OH.leaves}
+    assert np.linalg.norm(y - OH.matvec(x)) / np.linalg.norm(y) < 2 * eps
+
+
+def test_one_triangle_callback_generator_copy_and_recompression(built, oracle):
+    """Host-ACA build (Python generator), deep copy and SVD recompression keep the one-triangle tables consistent."""
+    import Htool
+
+    O = oracle
+    n, leaf, eps, eta = 2500, 20, 1e-6, 10.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H, cl, gen = _sym_build(pts, 0, 0.1, eps, eta, leaf, "L", native=False)
+    x = np.random.rand(n)
+    y_exact = O.dense_matvec(0, pts, pts, x, 0.1)
+    y = H * x
+    assert np.linalg.norm(y - y_exact) / np.linalg.norm(y_exact) < eps
+    H2 = copy.deepcopy(H)
+    assert np.array_equal(H2 * x, y)
+    del H
+    assert np.array_equal(H2 * x, y)
+    Htool.recompression(H2, 1e-3)
+    y3 = H2 * x
+    assert 1e-9 < np.linalg.norm(y3 - y_exact) / np.linalg.norm(y_exact) < 5e-3
+
+
+def test_one_triangle_falls_back_when_not_eligible(built, oracle):
+    """Rectangular / non-symmetric builds ignore the flag (both triangles stored, a warning is logged)."""
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    np.random.seed(0)
+    pts = O.points_in_sphere(1500)
+    cl = cluster_of(pts, 20)
+    b = Htool.HMatrixTreeBuilder(1e-3, 10.0, "N", "N")
+    b.set_symmetric_storage(True)
+    H = b.build(Htool.NativeGenerator("laplace", pts, pts, 0.0), cl, cl)
+    x = np.random.rand(1500)
+    y_exact = O.dense_matvec(1, pts, pts, x, 0.0)
+    assert np.linalg.norm(H * x - y_exact) / np.linalg.norm(y_exact) < 1e-3

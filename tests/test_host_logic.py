@@ -265,3 +265,19 @@ def test_mpi4py_standin_world_of_one(built):
     assert np.array_equal(send, recv)
     comm.Barrier()
     assert comm.bcast("x") == "x"
+
+
+def test_block_tree_queues_one_triangle(oracle):
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    np.random.seed(0)
+    pts = O.points_in_sphere(4000)
+    cl = cluster_of(pts, 25)
+    oc = O.Cluster(pts, max_leaf=25)
+    a, d = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L", one_triangle=True)
+    oa, od = O.blocktree(oc, oc, 10.0, "S", "L")
+    assert (len(a), len(d)) == (len(oa), len(od))
+    a2, d2 = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L")
+    assert len(a2) > len(a) and len(d2) > len(d)   # default storage keeps both triangles
