@@ -289,6 +289,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_ph, ph = H.phase_times_us()
+    exchange_us = None
+    if dist_mode and step is not None:
+        # the exchange on its own (reported separately; it is inside the timed steps as well)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gather(x_local)
+        torch.cuda.synchronize()
+        exchange_us = (time.perf_counter() - t1) / args.steps * 1e6
 
     tot_bytes = float(ab["total"])
     if args.check and dist_mode:
@@ -297,8 +307,14 @@ def main():
         y_user, x_user = np.zeros(n, dtype=np.complex128 if is_complex else np.float64), np.zeros(n, dtype=np.complex128 if is_complex else np.float64)
         y_user[perm] = SliceGatherer(sizes, dtype, "cuda")(y).cpu().numpy()
         x_user[perm] = SliceGatherer(sizes, dtype, "cuda")(x_local).cpu().numpy()
+    per_rank = None
     if dist_mode:
-        t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([tot_bytes, sum(ph) if n_ph else 0.0, exchange_us or 0.0, float(t_build)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"algorithmic_GB": float(v[0]) / 1e9, "product_us": float(v[1]), "exchange_us": float(v[2]), "build_s": float(v[3])} for v in allr]
+        t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -332,22 +348,27 @@ def main():
         "algorithmic_GB": tot_bytes / 1e9,
         "rhs_per_step": args.rhs,
         "symmetric_storage": args.symmetric,
+        "per_rank": per_rank,   # multi-GPU: bytes, product time (sum of its kernels, HIP events) and exchange time of every rank
         "gmres": None if gmres_info is None else {"iterations": gmres_info["iterations"], "s_per_iteration": dt / max(gmres_info["iterations"], 1),
                                                    "relative_residuals": [gmres_info["residuals"][i] for i in (0, len(gmres_info["residuals"]) // 2, -1)],
                                                    "note": "step = one GMRES iteration (1 product + CGS2 orthogonalisation) on (shift I + H), no preconditioner"},
     }
     if rank == 0:
         t_b = ph[3] * 1e-6 if n_ph else None
+        fused = args.symmetric == "one-triangle"
+        # one-triangle storage: the last event interval holds the fused sweep over the U / dense panels AND the second,
+        # transposed, read of the V panels
+        bytes_b = ab["phase_b"] + (ab["phase_a"] if fused else 0)
         out["roofline"] = {
             "bound": "hbm",
-            "kernel": "tile_gemv_wide (phase B: U and dense panels)",
-            "achieved": (ab["phase_b"] / t_b / 1e9) if t_b else None,
+            "kernel": "tile_gemv_wide_sym + tile_gemv_tall_transposed (fused sweep of the stored triangle)" if fused else "tile_gemv_wide (phase B: U and dense panels)",
+            "achieved": (bytes_b / t_b / 1e9) if t_b else None,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
-            "frac": (ab["phase_b"] / t_b / 1e9 / HBM_PEAK_GBPS) if t_b else None,
-            "traffic": pmc_traffic(args, n),
+            "frac": (bytes_b / t_b / 1e9 / HBM_PEAK_GBPS) if t_b else None,
+            "traffic": None if args.symmetric else pmc_traffic(args, n),
             "launch_us": ph[3] if n_ph else None,
-            "algorithmic_bytes_per_launch": ab["phase_b"],
+            "algorithmic_bytes_per_launch": bytes_b,
             "launches_averaged": n_ph,
             "other_kernels_us": {"x_gather": ph[0], "phase_a_tile_gemv_tall": ph[1], "phase_a2_tile_gemv_tall": ph[2]} if n_ph else None,
             "phase_a_achieved": (ab["phase_a"] / (ph[1] * 1e-6) / 1e9) if n_ph and ph[1] > 0 else None,

@@ -213,74 +213,82 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
     typedef typename Ops::T T;
     constexpr int TM = 64 * Ops::RPL;
     const GTile tl = tiles[blockIdx.x];
-    const GSeg sg = segs[tl.seg_begin];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = lane * Ops::RPL;
-    const int nq = (tl.nrows + TM - 1) / TM;
-    const int ncols = sg.ncols;
-    // all row chunks of a tile share the columns, hence the coefficients: with at most 64 columns (always the
-    // case in phase A, where the columns are one source tile) they are fetched once per wave, not per chunk
-    const bool single = ncols <= 64;
-    T coef1[NR];
+    // a tile holds one panel per batch (segment); the row chunks of all of them are dealt round-robin to the 4 waves
+    int flat = 0;
+    for (int s = 0; s < tl.nseg; s++) {
+        const GSeg sg = segs[tl.seg_begin + s];
+        GTile ot = tl;
+        if (sg.oidx) ot.omap = sg.oidx;
+        const int nrows = sg.nrows_t;
+        const int nq = (nrows + TM - 1) / TM;
+        const int ncols = sg.ncols;
+        // all row chunks of a panel share the columns, hence the coefficients: with at most 64 columns they are
+        // fetched once per wave, not per chunk
+        const bool single = ncols <= 64;
+        T coef1[NR];
 #pragma unroll
-    for (int r = 0; r < NR; r++) coef1[r] = Ops::zero();
-    if (single && lane < ncols) {
-        const long long ci = sg.cidx[lane];
+        for (int r = 0; r < NR; r++) coef1[r] = Ops::zero();
+        if (single && lane < ncols) {
+            const long long ci = sg.cidx[lane];
 #pragma unroll
-        for (int r = 0; r < NR; r++) coef1[r] = W[r * w_stride + ci];
-    }
-    for (int q = wave; q < nq; q += 4) {
-        const int rows_here = min(TM, tl.nrows - q * TM);
-        const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
-        const bool active = row0 < rows_here;
-        const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0;
-        double2 acc[NR];
+            for (int r = 0; r < NR; r++) coef1[r] = W[r * w_stride + ci];
+        }
+        for (int q = (wave + 4 - (flat & 3)) & 3; q < nq; q += 4) {
+            const int rows_here = min(TM, nrows - q * TM);
+            const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
+            const bool active = row0 < rows_here;
+            const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0;
+            double2 acc[NR];
 #pragma unroll
-        for (int r = 0; r < NR; r++) acc[r] = make_double2(0.0, 0.0);
-        for (int c0 = 0; c0 < ncols; c0 += 64) {
-            const int nc = min(64, ncols - c0);
-            T coef[NR];
+            for (int r = 0; r < NR; r++) acc[r] = make_double2(0.0, 0.0);
+            for (int c0 = 0; c0 < ncols; c0 += 64) {
+                const int nc = min(64, ncols - c0);
+                T coef[NR];
 #pragma unroll
-            for (int r = 0; r < NR; r++) coef[r] = coef1[r];
-            if (!single && lane < nc) {
-                const long long ci = sg.cidx[c0 + lane];
+                for (int r = 0; r < NR; r++) coef[r] = coef1[r];
+                if (!single && lane < nc) {
+                    const long long ci = sg.cidx[c0 + lane];
 #pragma unroll
-                for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
-            }
-            for (int cc = 0; cc < nc; cc += CH) {
-                const T *p = base + (long long)(c0 + cc) * ld;
-                if (NR > 1 && panel_stride != 0) {
-                    for (int u = 0; cc + u < nc && u < CH; u++) {
+                    for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
+                }
+                for (int cc = 0; cc < nc; cc += CH) {
+                    const T *p = base + (long long)(c0 + cc) * ld;
+                    if (NR > 1 && panel_stride != 0) {
+                        for (int u = 0; cc + u < nc && u < CH; u++) {
 #pragma unroll
-                        for (int r = 0; r < NR; r++) {
-                            double2 v = active ? *(const double2 *)(p + u * ld + r * panel_stride) : make_double2(0.0, 0.0);
-                            Ops::fma(acc[r], v, Ops::bcast(coef[r], cc + u));
+                            for (int r = 0; r < NR; r++) {
+                                double2 v = active ? *(const double2 *)(p + u * ld + r * panel_stride) : make_double2(0.0, 0.0);
+                                Ops::fma(acc[r], v, Ops::bcast(coef[r], cc + u));
+                            }
                         }
-                    }
-                } else if (cc + CH <= nc) {
-                    double2 v[CH];
+                    } else if (cc + CH <= nc) {
+                        double2 v[CH];
 #pragma unroll
-                    for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+                        for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int u = 0; u < CH; u++) {
+                        for (int u = 0; u < CH; u++) {
 #pragma unroll
-                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], cc + u));
-                    }
-                } else { // tail group: same unrolled batch, loads predicated (coefficients beyond nc are zero)
-                    double2 v[CH];
+                            for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], cc + u));
+                        }
+                    } else { // tail group: same unrolled batch, loads predicated (coefficients beyond nc are zero)
+                        double2 v[CH];
 #pragma unroll
-                    for (int u = 0; u < CH; u++) v[u] = (active && cc + u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
+                        for (int u = 0; u < CH; u++) v[u] = (active && cc + u < nc) ? ldnt16(p + u * ld) : make_double2(0.0, 0.0);
 #pragma unroll
-                    for (int u = 0; u < CH; u++) {
+                        for (int u = 0; u < CH; u++) {
 #pragma unroll
-                        for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], (cc + u) & 63));
+                            for (int r = 0; r < NR; r++) Ops::fma(acc[r], v[u], Ops::bcast(coef[r], (cc + u) & 63));
+                        }
                     }
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < NR; r++) store_rows<Ops>(out + r * out_stride, tl, q * TM + row0, tl.nrows, acc[r]);
+            for (int r = 0; r < NR; r++) store_rows<Ops>(out + r * out_stride, ot, q * TM + row0, nrows, acc[r]);
+        }
+        flat += nq;
     }
 }
 
@@ -942,36 +950,65 @@ struct DeviceBuilder {
         for (size_t b = 0; b < tabs.size(); b++)
             for (int c = 0; c < nct; c++) total_chunks += (tabs[b].a_nrows[c] + TM - 1) / TM;
         const int qmax = (int)std::max<long long>(4, ((total_chunks + target_items - 1) / target_items + 3) / 4 * 4);
-        for (size_t b = 0; b < tabs.size(); b++)
+        // phase A tiles.  Many source tiles (large operators): ONE workgroup per source tile streams the panels of all
+        // batches (a segment each), so that its four waves stay busy even when a batch holds only a chunk or two of the
+        // tile.  Few source tiles: one workgroup per (batch, piece of at most qmax row chunks) for parallelism.
+        const bool merge_batches = nct >= target_items / 2;
+        auto tall_segment = [&](size_t b, int c, int nr) {
+            const int nq = (nr + TM - 1) / TM, rem = nr - (nq - 1) * TM;
+            GSeg s;
+            s.panel = (const char *)D->batches[b].panelA + (size_t)tabs[b].a_pbase[c] * sizeof(T);
+            s.cidx = D->iota + (H.ctiles.off[c] - H.col_off);
+            s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.nrows_t = nr;
+            s.chunk_stride = (long long)H.ctiles.size[c] * TM;
+            s.oidx = D->batches[b].oidxA + tabs[b].a_obase[c];
+            return s;
+        };
+        if (merge_batches) {
             for (int c = 0; c < nct; c++) {
-                int nr = tabs[b].a_nrows[c];
-                if (nr == 0) continue;
-                int nq = (nr + TM - 1) / TM, rem = nr - (nq - 1) * TM;
-                GSeg s;
-                s.panel = (const char *)D->batches[b].panelA + (size_t)tabs[b].a_pbase[c] * sizeof(T);
-                s.cidx = D->iota + (H.ctiles.off[c] - H.col_off);
-                s.ncols = H.ctiles.size[c]; s.ld_full = TM; s.ld_last = (rem + vec_rows - 1) / vec_rows * vec_rows; s.nrows_t = 0;
-                s.chunk_stride = (long long)H.ctiles.size[c] * TM;
-                // cut tall tiles into pieces of at most qmax row chunks (independent outputs, no reduction)
-                for (int q0 = 0; q0 < nq; q0 += qmax) {
-                    const int q1 = std::min(nq, q0 + qmax);
-                    GSeg sp = s;
-                    sp.panel = (const char *)s.panel + (size_t)q0 * (size_t)s.chunk_stride * sizeof(T);
-                    if (q1 < nq) sp.ld_last = TM;
-                    GTile t;
-                    t.seg_begin = (long long)segs.size(); t.nseg = 1;
-                    t.nrows = (q1 < nq ? q1 * TM : nr) - q0 * TM;
-                    t.omap = D->batches[b].oidxA + tabs[b].a_obase[c] + (long long)q0 * TM; t.out_begin = 0;
-                    segs.push_back(sp);
-                    tA.push_back(t);
-                    wA.push_back((double)t.nrows * s.ncols);
+                GTile t;
+                t.seg_begin = (long long)segs.size(); t.nseg = 0; t.nrows = 0; t.omap = nullptr; t.out_begin = 0;
+                double work = 0;
+                for (size_t b = 0; b < tabs.size(); b++) {
+                    const int nr = tabs[b].a_nrows[c];
+                    if (nr == 0) continue;
+                    segs.push_back(tall_segment(b, c, nr));
+                    t.nseg++;
+                    t.nrows += nr;
+                    work += (double)nr * H.ctiles.size[c];
                 }
+                if (t.nseg) { tA.push_back(t); wA.push_back(work); }
             }
+        } else {
+            for (size_t b = 0; b < tabs.size(); b++)
+                for (int c = 0; c < nct; c++) {
+                    const int nr = tabs[b].a_nrows[c];
+                    if (nr == 0) continue;
+                    const GSeg s = tall_segment(b, c, nr);
+                    const int nq = (nr + TM - 1) / TM;
+                    // cut tall tiles into pieces of at most qmax row chunks (independent outputs, no reduction)
+                    for (int q0 = 0; q0 < nq; q0 += qmax) {
+                        const int q1 = std::min(nq, q0 + qmax);
+                        GSeg sp = s;
+                        sp.panel = (const char *)s.panel + (size_t)q0 * (size_t)s.chunk_stride * sizeof(T);
+                        if (q1 < nq) sp.ld_last = TM;
+                        sp.nrows_t = (q1 < nq ? q1 * TM : nr) - q0 * TM;
+                        sp.oidx = s.oidx + (long long)q0 * TM;
+                        GTile t;
+                        t.seg_begin = (long long)segs.size(); t.nseg = 1;
+                        t.nrows = sp.nrows_t;
+                        t.omap = nullptr; t.out_begin = 0;
+                        segs.push_back(sp);
+                        tA.push_back(t);
+                        wA.push_back((double)t.nrows * s.ncols);
+                    }
+                }
+        }
         for (size_t b = 0; b < tabs.size(); b++)
             for (auto &r : tabs[b].reduces) {
                 GSeg s;
                 s.panel = (const char *)D->W + (size_t)r.w_panel * sizeof(T);
-                s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.nrows_t = 0; s.chunk_stride = TM;
+                s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.nrows_t = r.nrows; s.chunk_stride = TM;
                 GTile t;
                 t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = r.nrows; t.omap = nullptr; t.out_begin = r.out_base;
                 segs.push_back(s);
@@ -1083,7 +1120,7 @@ struct DeviceBuilder {
                 for (auto &r : tabs[b].z_reduces) {
                     GSeg s;
                     s.panel = (const char *)D->W + (size_t)r.w_panel * sizeof(T);
-                    s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.nrows_t = 0; s.chunk_stride = TM;
+                    s.cidx = D->ones_idx; s.ncols = r.ncols; s.ld_full = r.ld; s.ld_last = r.ld; s.nrows_t = r.nrows; s.chunk_stride = TM;
                     GTile t;
                     t.seg_begin = (long long)segs.size(); t.nseg = 1; t.nrows = r.nrows; t.omap = nullptr; t.out_begin = r.out_base;
                     segs.push_back(s);
@@ -1430,7 +1467,7 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     fix_tiles(S->tilesZ, S->nZ, &D->tilesZ);
     if (S->ypart) D->ypart = dup_alloc(S->ypart);
     segs.resize((size_t)nseg_used);
-    for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); s.zidx = (const int *)reloc(s.zidx); }
+    for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); s.zidx = (const int *)reloc(s.zidx); s.oidx = (const int *)reloc(s.oidx); }
     D->segs = upload(segs);
     (void)es;
 }

@@ -22,8 +22,9 @@ struct GSeg {
     int ncols;
     int ld_full;           // leading dimension of full row chunks
     int ld_last;           // leading dimension of the last (or only) row chunk
-    int nrows_t = 0;       // rows of the panel (transposed use of a tall panel only)
+    int nrows_t = 0;       // rows of the panel (tall panels: a tile may hold several, one per batch)
     long long chunk_stride; // elements between consecutive row chunks
+    const int *oidx = nullptr;      // tall panels: output index of every row (null: the tile's omap / out_begin)
     const int *zidx = nullptr;      // one-triangle storage: per column, where its transposed dot product goes in W (-1: nowhere);
                             // for the transposed use of a tall panel: per row, the index in W of its coefficient
 };
