@@ -112,15 +112,22 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
             const T *base = (const T *)sg.panel + row0;
             const long long ld = sg.ld_last;
             const int ncols = sg.ncols;
+            // the coefficient INDEX of a batch is fetched one batch ahead, so that the dependent chain index ->
+            // coefficient never leaves a wave without loads in flight
+            int ci = 0;
+            if (wave * CH + lane < ncols && lane < CH) ci = sg.cidx[wave * CH + lane];
             for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
                 const int nc = min(CH, ncols - c0);
                 T coef[NR];
 #pragma unroll
                 for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
                 if (lane < nc) {
-                    const long long ci = sg.cidx[c0 + lane];
 #pragma unroll
                     for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
+                }
+                {
+                    const int c1 = c0 + 4 * CH;
+                    if (c1 + lane < ncols && lane < CH) ci = sg.cidx[c1 + lane];
                 }
                 const T *p = base + (long long)c0 * ld;
                 if (nc == CH) {
@@ -155,20 +162,30 @@ __global__ __launch_bounds__(256) void tile_gemv_wide(const GTile *__restrict__ 
             const long long ld = sg.ld_last;
             const T *base = (const T *)sg.panel + row0 + (long long)g * ld;
             const int ncols = sg.ncols;
+            int ci = 0;
+            if (wave * GC + lane < ncols && lane < GC) ci = sg.cidx[wave * GC + lane];
             for (int c0 = wave * GC; c0 < ncols; c0 += 4 * GC) {
                 const int nc = min(GC, ncols - c0);
                 T coef[NR];
 #pragma unroll
                 for (int r = 0; r < NR; r++) coef[r] = Ops::zero();
                 if (lane < nc) {
-                    const long long ci = sg.cidx[c0 + lane];
 #pragma unroll
                     for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
                 }
+                {
+                    const int c1 = c0 + 4 * GC;
+                    if (c1 + lane < ncols && lane < GC) ci = sg.cidx[c1 + lane];
+                }
                 const T *p = base + (long long)c0 * ld;
                 double2 v[CH];
+                if (nc == GC) {
 #pragma unroll
-                for (int u = 0; u < CH; u++) v[u] = (active && u * F + g < nc) ? ldnt16(p + (long long)(u * F) * ld) : make_double2(0.0, 0.0);
+                    for (int u = 0; u < CH; u++) v[u] = active ? ldnt16(p + (long long)(u * F) * ld) : make_double2(0.0, 0.0);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CH; u++) v[u] = (active && u * F + g < nc) ? ldnt16(p + (long long)(u * F) * ld) : make_double2(0.0, 0.0);
+                }
 #pragma unroll
                 for (int u = 0; u < CH; u++) {
 #pragma unroll
@@ -225,22 +242,32 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
         const int nrows = sg.nrows_t;
         const int nq = (nrows + TM - 1) / TM;
         const int ncols = sg.ncols;
-        // all row chunks of a panel share the columns, hence the coefficients: with at most 64 columns they are
-        // fetched once per wave, not per chunk
-        const bool single = ncols <= 64;
-        T coef1[NR];
+        // all row chunks of a panel share the columns, hence the coefficients: with at most 128 columns (always in
+        // phase A, where the columns are one source tile) they are fetched once per panel, not per chunk
+        const bool hoisted = ncols <= 128;
+        T coef1[NR], coef2[NR];
 #pragma unroll
-        for (int r = 0; r < NR; r++) coef1[r] = Ops::zero();
-        if (single && lane < ncols) {
+        for (int r = 0; r < NR; r++) coef1[r] = coef2[r] = Ops::zero();
+        if (hoisted && lane < ncols) {
             const long long ci = sg.cidx[lane];
 #pragma unroll
             for (int r = 0; r < NR; r++) coef1[r] = W[r * w_stride + ci];
+        }
+        if (hoisted && 64 + lane < ncols) {
+            const long long ci = sg.cidx[64 + lane];
+#pragma unroll
+            for (int r = 0; r < NR; r++) coef2[r] = W[r * w_stride + ci];
         }
         for (int q = (wave + 4 - (flat & 3)) & 3; q < nq; q += 4) {
             const int rows_here = min(TM, nrows - q * TM);
             const long long ld = (q == nq - 1) ? sg.ld_last : sg.ld_full;
             const bool active = row0 < rows_here;
             const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0;
+            // where the lane's rows go: fetched now, used after the chunk has been streamed
+            const int rr = q * TM + row0;
+            long long oi0 = -1, oi1 = -1;
+            if (rr < nrows) oi0 = ot.omap ? (long long)ot.omap[rr] : ot.out_begin + rr;
+            if (Ops::RPL == 2 && rr + 1 < nrows) oi1 = ot.omap ? (long long)ot.omap[rr + 1] : ot.out_begin + rr + 1;
             double2 acc[NR];
 #pragma unroll
             for (int r = 0; r < NR; r++) acc[r] = make_double2(0.0, 0.0);
@@ -248,8 +275,8 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
                 const int nc = min(64, ncols - c0);
                 T coef[NR];
 #pragma unroll
-                for (int r = 0; r < NR; r++) coef[r] = coef1[r];
-                if (!single && lane < nc) {
+                for (int r = 0; r < NR; r++) coef[r] = c0 == 0 ? coef1[r] : coef2[r];
+                if (!hoisted && lane < nc) {
                     const long long ci = sg.cidx[c0 + lane];
 #pragma unroll
                     for (int r = 0; r < NR; r++) coef[r] = W[r * w_stride + ci];
@@ -286,7 +313,16 @@ __global__ __launch_bounds__(256) void tile_gemv_tall(const GTile *__restrict__ 
                 }
             }
 #pragma unroll
-            for (int r = 0; r < NR; r++) store_rows<Ops>(out + r * out_stride, ot, q * TM + row0, nrows, acc[r]);
+            for (int r = 0; r < NR; r++) {
+                if (Ops::RPL == 2) {
+                    double *o = (double *)(out + r * out_stride);
+                    if (oi0 >= 0) o[oi0] = acc[r].x;
+                    if (oi1 >= 0) o[oi1] = acc[r].y;
+                } else {
+                    double2 *o = (double2 *)(out + r * out_stride);
+                    if (oi0 >= 0) o[oi0] = acc[r];
+                }
+            }
         }
         flat += nq;
     }
@@ -351,10 +387,16 @@ __global__ __launch_bounds__(256) void tile_gemv_wide_sym(const GTile *__restric
         const T *base = (const T *)sg.panel + row0;
         const long long ld = sg.ld_last;
         const int ncols = sg.ncols;
+        int ci = 0; // coefficient index of the next batch, fetched one batch ahead (see tile_gemv_wide)
+        if (wave * CH + lane < ncols && lane < CH) ci = sg.cidx[wave * CH + lane];
         for (int c0 = wave * CH; c0 < ncols; c0 += 4 * CH) {
             const int nc = min(CH, ncols - c0);
             T coef = Ops::zero();
-            if (lane < nc) coef = W[sg.cidx[c0 + lane]];
+            if (lane < nc) coef = W[ci];
+            {
+                const int c1 = c0 + 4 * CH;
+                if (c1 + lane < ncols && lane < CH) ci = sg.cidx[c1 + lane];
+            }
             const T *p = base + (long long)c0 * ld;
             double2 v[CH];
             if (nc == CH) {

@@ -375,3 +375,35 @@ def test_recompression_complex(built, oracle):
         assert abs(U1.shape[1] - r_ref) <= 1
         assert np.linalg.norm(U1 @ V1 - A0) <= 1.05 * eps * np.linalg.norm(A0)
     assert same >= 0.9 * len(sel)
+
+
+@pytest.mark.parametrize("arena_mb", [2, 12, 40])
+def test_multi_round_build_with_held_factors(built, oracle, monkeypatch, arena_mb):
+    """A small temporary arena forces several ACA rounds: finished factors are compacted to the front of the arena and
+    packed in few batches (2 MB: leaves larger than the staging buffer take the direct path).  The operator must be
+    the one a single-round build gives, bit for bit at leaf level."""
+    O = oracle
+    n, leaf, eps, eta = 12000, 40, 1e-5, 10.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H1, _, _ = _build(pts, pts, 1, 0.0, eps, eta, leaf)
+    monkeypatch.setenv("HTOOL_BUILD_ARENA_MB", str(arena_mb))
+    H2, _, _ = _build(pts, pts, 1, 0.0, eps, eta, leaf)
+    monkeypatch.delenv("HTOOL_BUILD_ARENA_MB")
+    L1, L2 = np.asarray(H1.leaves()), np.asarray(H2.leaves())
+    k1 = {tuple(l[:4]): (i, int(l[4])) for i, l in enumerate(L1)}
+    k2 = {tuple(l[:4]): (i, int(l[4])) for i, l in enumerate(L2)}
+    assert {k: v[1] for k, v in k1.items()} == {k: v[1] for k, v in k2.items()}
+    rng = np.random.RandomState(0)
+    keys = list(k1)
+    for j in rng.choice(len(keys), 60, replace=False):
+        A1, B1 = H1.leaf_panels(k1[keys[j]][0])
+        A2, B2 = H2.leaf_panels(k2[keys[j]][0])
+        assert np.array_equal(np.asarray(A1), np.asarray(A2))
+        if k1[keys[j]][1] > 0:
+            assert np.array_equal(np.asarray(B1), np.asarray(B2))
+    x = np.random.rand(n)
+    y1, y2 = H1 * x, H2 * x
+    assert np.linalg.norm(y1 - y2) / np.linalg.norm(y1) < 1e-13
+    y_exact = O.dense_matvec(1, pts, pts, x, 0.0)
+    assert np.linalg.norm(y2 - y_exact) / np.linalg.norm(y_exact) < eps
