@@ -26,10 +26,16 @@ def _plot_cluster(ax, cluster, coordinates, depth):
         colors[idx] = c
         mask[idx] = True
     pts = coordinates[:, mask]
-    if coordinates.shape[0] == 2:
-        ax.scatter(pts[0], pts[1], c=colors[mask], marker="o", s=10)
-    else:
-        ax.scatter(pts[0], pts[1], pts[2], c=colors[mask], marker="o", s=10)
+    # colour table chosen by the number of clusters shown, as the reference does (cluster.hpp:50-62); the points are
+    # handed over positionally (x, y[, z]) without a size argument, so that 3-D points on a plain 2-D Axes behave as
+    # they do there (tests/test_cluster.py:39)
+    import matplotlib.pyplot as plt
+    from matplotlib.colors import Normalize
+
+    n_shown = len(sel)
+    name = "Dark2" if n_shown < 9 else "Set1" if n_shown == 9 else "tab10" if n_shown == 10 else "tab20"
+    rgba = plt.get_cmap(name)(Normalize(vmin=colors[mask].min(), vmax=colors[mask].max())(colors[mask]))
+    ax.scatter(*[pts[k] for k in range(coordinates.shape[0])], c=rgba, marker="o")
 
 
 def _plot_hmatrix(ax, hmatrix):

@@ -246,11 +246,17 @@ def test_cluster_plot_runs(built, dimension):
     Htool.plot(axes[2], local, pts, 1)
     Htool.plot(axes[3], local, pts, 2)
     # depth-1 colouring of the root = the two partitions
-    assert len(np.unique(np.asarray(axes[0].collections[0].get_array()))) == 2
+    assert len(np.unique(np.asarray(axes[0].collections[0].get_facecolors()), axis=0)) == 2
     # the partition sub-tree only draws its own points
     n_local = axes[2].collections[0].get_offsets().shape[0] if dimension == 2 else len(axes[2].collections[0]._offsets3d[0])
     assert n_local == local.get_size()
     plt.close(fig)
+    if dimension == 3:  # the reference's own test draws 3-D points on plain 2-D axes (tests/test_cluster.py:38-42)
+        _, ax = plt.subplots(2, 2)
+        Htool.plot(ax[0, 0], cl, pts, 1)
+        Htool.plot(ax[1, 1], local, pts, 2)
+        assert ax[0, 0].collections[0].get_offsets().shape[0] == 500
+        plt.close("all")
 
 
 def test_mpi4py_standin_world_of_one(built):
