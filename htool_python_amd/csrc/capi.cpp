@@ -192,9 +192,9 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     H.params.dense_blocks = params->dense_blocks;
     H.params.dense_blocks_ctx = params->dense_blocks_ctx;
     if (params->store_one_triangle) {
-        const bool eligible = params->symmetry == 'S' && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition < 0 && source_partition < 0;
+        const bool eligible = (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition < 0 && source_partition < 0;
         if (eligible) { H.params.store_one_triangle = 1; H.one_triangle = true; }
-        else log_message(LOG_WARNING, "store_one_triangle needs symmetry 'S' with UPLO 'L'/'U' on one cluster tree without partition restriction: storing both triangles");
+        else log_message(LOG_WARNING, "store_one_triangle needs symmetry 'S' or 'H' with UPLO 'L'/'U' on one cluster tree without partition restriction: storing both triangles");
     }
     if (target_partition >= 0) {
         HM_CHECK(target_partition < (int)T->part_nodes.size(), "target_partition_number out of range");
@@ -506,7 +506,7 @@ int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluste
     P.uplo = params->uplo;
     P.min_target_depth = params->minimal_target_depth;
     P.min_source_depth = params->minimal_source_depth;
-    if (params->store_one_triangle && params->symmetry == 'S' && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition_number < 0)
+    if (params->store_one_triangle && (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition_number < 0)
         P.store_one_triangle = 1;
     int t_root = 0;
     if (target_partition_number >= 0) {

@@ -363,7 +363,8 @@ __device__ __forceinline__ void lane_transpose_reduce16(typename Ops::T *d, int 
 // column c with zidx[c] >= 0:  Wz[zidx[c]] = sum_i panel[c][i] * x[xoff + i]   (x = W[0 : n), cluster numbering)
 template <typename Ops>
 __global__ __launch_bounds__(256) void tile_gemv_wide_sym(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
-                                                          const typename Ops::T *W, typename Ops::T *Wz, typename Ops::T *__restrict__ out) {
+                                                          const typename Ops::T *W, typename Ops::T *Wz, typename Ops::T *__restrict__ out, int conj_t) {
+    // conj_t: Hermitian operator ('H'): the second use of a leaf is its conjugate transpose
     typedef typename Ops::T T;
     constexpr int CH = 16;
     const GTile tl = tiles[blockIdx.x];
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void tile_gemv_wide_sym(const GTile *__restric
             for (int u = 0; u < CH; u++) {
                 Ops::fma(acc, v[u], Ops::bcast(coef, u));
                 d[u] = Ops::zero();
+                if (Ops::RPL == 1 && conj_t) v[u].y = -v[u].y;
                 Ops::tacc(d[u], v[u], xl);
             }
             lane_transpose_reduce16<Ops>(d, lane);
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void tile_gemv_wide_sym(const GTile *__restric
 // tl.nrows source positions j of the tile, over all segments (one per batch).  Wave w owns columns [w*CG, (w+1)*CG).
 template <typename Ops>
 __global__ __launch_bounds__(256) void tile_gemv_tall_transposed(const GTile *__restrict__ tiles, const GSeg *__restrict__ segs,
-                                                                 const typename Ops::T *__restrict__ W, typename Ops::T *ycl) {
+                                                                 const typename Ops::T *__restrict__ W, typename Ops::T *ycl, int conj_t) {
     typedef typename Ops::T T;
     constexpr int TM = 64 * Ops::RPL;
     constexpr int CG = TM / 4; // columns per wave: 32 (real) / 16 (complex)
@@ -478,6 +480,7 @@ __global__ __launch_bounds__(256) void tile_gemv_tall_transposed(const GTile *__
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
                     if (Ops::RPL == 2 && !second) v[u].y = 0.0; // the padding row of an odd last chunk is never written
+                    if (Ops::RPL == 1 && conj_t) v[u].y = -v[u].y;
                     Ops::tacc(acc[cc + u], v[u], z);
                 }
             }
@@ -949,6 +952,7 @@ struct DeviceBuilder {
         for (auto &bt : tabs) for (auto &r : bt.reduces) maxP = std::max(maxP, r.ncols);
         for (auto &bt : tabs) for (auto &r : bt.z_reduces) maxP = std::max(maxP, r.ncols);
         D->one_triangle = H.one_triangle;
+        D->conj_transposed = H.one_triangle && H.is_complex && H.params.symmetry == 'H';
         std::vector<int> ones(maxP, Ns);
         D->ones_idx = upload(ones, &D->table_bytes);
         HIP_OK(hipMalloc(&D->x_tmp, (size_t)std::max(Ns, 1) * sizeof(T)));
@@ -1245,9 +1249,9 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
         // use of the V panels, then the transposed dense results and the scatter to the caller's numbering
         if constexpr (NR == 1) {
             T *ycl = (T *)D->ycl;
-            if (D->nB) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const T *)W, W, ycl);
+            if (D->nB) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const T *)W, W, ycl, D->conj_transposed ? 1 : 0);
             if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, 1>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, 0LL);
-            if (D->nAT) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl);
+            if (D->nAT) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, D->conj_transposed ? 1 : 0);
             if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym_kernel<T>, dim3(D->n_zd_tiles), dim3(128), 0, st, (const T *)ycl, (const T *)W, D->zd_ptr, D->zd_woff, D->zd_rows,
                                                   out_user ? D->perm_t : (const int *)nullptr, (T *)y_dev);
         } else {

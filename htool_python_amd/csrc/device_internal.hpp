@@ -70,6 +70,7 @@ struct DeviceHMatrix {
     int splitB = 1, nB_split = 0;
     // one-triangle storage of a symmetric operator: extra tables and a cluster-numbered accumulator for y
     bool one_triangle = false;
+    bool conj_transposed = false;   // 'H': the second use of a stored leaf is its conjugate transpose
     GTile *tilesAT = nullptr, *tilesZ = nullptr; // transposed use of the tall panels; sums of the transposed partials
     int nAT = 0, nZ = 0;
     int *zd_ptr = nullptr;          // per row tile: range of zd_woff entries to add

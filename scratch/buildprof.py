@@ -2,16 +2,22 @@ import logging, time, sys
 logging.basicConfig(level=logging.DEBUG, stream=sys.stderr)
 import numpy as np, torch, Htool
 from htool_python_amd.workloads import points_in_sphere
-n=1_000_000
+kernel = sys.argv[1] if len(sys.argv) > 1 else "laplace"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 pts=points_in_sphere(n, seed=0)
 Htool.set_num_threads(16)
-for rep in range(3):
+for rep in range(reps):
     t0=time.time()
     cb=Htool.ClusterTreeBuilder(); cb.set_maximal_leaf_size(100)
     cl=cb.create_cluster_tree(pts,2,size_of_partition=1)
     t1=time.time()
-    gen=Htool.NativeGenerator("laplace",pts,pts,0.0)
-    b=Htool.HMatrixTreeBuilder(1e-3,10.0,"N","N")
+    if kernel == "helmholtz":
+        gen=Htool.ComplexNativeGenerator("helmholtz",pts,pts,10.0)
+        b=Htool.ComplexHMatrixTreeBuilder(1e-3,10.0,"N","N")
+    else:
+        gen=Htool.NativeGenerator("laplace",pts,pts,0.0)
+        b=Htool.HMatrixTreeBuilder(1e-3,10.0,"N","N")
     torch.cuda.synchronize(); t2=time.time()
     H=b.build(gen,cl,cl)
     torch.cuda.synchronize(); t3=time.time()

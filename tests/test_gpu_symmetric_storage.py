@@ -153,3 +153,40 @@ def test_one_triangle_falls_back_when_not_eligible(built, oracle):
     x = np.random.rand(1500)
     y_exact = O.dense_matvec(1, pts, pts, x, 0.0)
     assert np.linalg.norm(H * x - y_exact) / np.linalg.norm(y_exact) < 1e-3
+
+
+def test_one_triangle_hermitian(built, oracle):
+    """'H': the second use of a stored leaf is its conjugate transpose.  Hermitian test kernel
+    exp(i (theta_i - theta_j)) / (0.1 + |x_i - x_j|) through a Python generator (host ACA)."""
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    n, leaf, eps, eta = 2000, 25, 1e-5, 10.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    theta = 3.0 * pts[0]
+
+    class HermitianGenerator(Htool.ComplexVirtualGenerator):
+        def build_submatrix(self, J, K, mat):
+            mat[:, :] = np.exp(1j * (theta[J][:, None] - theta[K][None, :])) * O.kernel_block(0, pts[:, J], pts[:, K], 0.1)
+
+    A = np.exp(1j * (theta[:, None] - theta[None, :])) * O.kernel_block(0, pts, pts, 0.1)
+    assert np.abs(A - A.conj().T).max() == 0
+    cl = cluster_of(pts, leaf)
+    x = np.random.rand(n) + 1j * np.random.rand(n)
+    results = {}
+    for uplo in ("L", "U"):
+        b = Htool.ComplexHMatrixTreeBuilder(eps, eta, "H", uplo)
+        b.set_symmetric_storage(True)
+        gen = HermitianGenerator()
+        H = b.build(gen, cl, cl)
+        L = np.asarray(H.leaves())
+        assert all((l[2] < l[0] + l[1]) if uplo == "L" else (l[0] < l[2] + l[3]) for l in L)
+        y = H * x
+        assert np.linalg.norm(y - A @ x) / np.linalg.norm(A @ x) < eps
+        D = H.to_dense_in_user_numbering()
+        assert np.linalg.norm(D - A) / np.linalg.norm(A) < eps
+        assert np.abs(D - D.conj().T).max() < 1e-12 * np.abs(D).max()
+        results[uplo] = y
+    assert np.linalg.norm(results["L"] - results["U"]) / np.linalg.norm(results["L"]) < 2 * eps
