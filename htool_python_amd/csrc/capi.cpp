@@ -160,6 +160,7 @@ void htool_build_params_default(htool_build_params *p) {
     p->uplo = 'N';
     p->reqrank = -1;
     p->block_tree_consistency = 1;
+    p->store_one_triangle = 1;
 }
 
 // ---- H-matrix ----------------------------------------------------------------------------------
@@ -194,7 +195,7 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     if (params->store_one_triangle) {
         const bool eligible = (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition < 0 && source_partition < 0;
         if (eligible) { H.params.store_one_triangle = 1; H.one_triangle = true; }
-        else log_message(LOG_WARNING, "store_one_triangle needs symmetry 'S' or 'H' with UPLO 'L'/'U' on one cluster tree without partition restriction: storing both triangles");
+        else if (params->symmetry != 'N') log_message(LOG_DEBUG, "symmetric build restricted to a partition or on two cluster trees: both triangles of the requested rows are stored");
     }
     if (target_partition >= 0) {
         HM_CHECK(target_partition < (int)T->part_nodes.size(), "target_partition_number out of range");

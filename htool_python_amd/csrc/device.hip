@@ -865,6 +865,7 @@ struct DeviceBuilder {
         bt.b_pbase.swap(L.b_pbase); bt.b_cbase.swap(L.b_cbase); bt.a_pbase.swap(L.a_pbase); bt.a_obase.swap(L.a_obase);
         bt.reduces.swap(L.reduces);
         bt.z_reduces.swap(L.z_reduces); bt.zd_tile.swap(L.zd_tile); bt.zd_woff.swap(L.zd_woff);
+        bt.r_end = H.r_elems;
         owned.ptrs.clear(); // success: ownership moves to the device H-matrix
         if (replace_index >= 0) {
             DevBatch &old = D->batches[replace_index];

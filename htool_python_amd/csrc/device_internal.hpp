@@ -54,6 +54,7 @@ struct BatchTables {
     std::vector<BatchLayout::Reduce> z_reduces;
     std::vector<int> zd_tile;
     std::vector<int64_t> zd_woff;
+    int64_t r_end = 0;   // end of the part of the R workspace this batch's layout refers to
 };
 
 struct DeviceHMatrix {

@@ -564,7 +564,7 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("set_low_rank_generator", [](B &b, py::object g) { b.low_rank = g.cast<std::shared_ptr<PyVirtualLowRankGenerator<T>>>(); b.low_rank_ref = g; })
         .def("set_dense_blocks_generator", [](B &b, py::object g) { b.dense_blocks = g.cast<std::shared_ptr<PyVirtualDenseBlocksGenerator<T>>>(); b.dense_blocks_ref = g; })
         .def("set_block_tree_consistency", [](B &b, bool c) { b.p.block_tree_consistency = c ? 1 : 0; })
-        // extension: keep the UPLO triangle only for symmetry 'S' (the reference's storage; default here is both triangles)
+        // extension: False stores both triangles of a symmetric operator (default: the UPLO triangle only, as the reference does)
         .def("set_symmetric_storage", [](B &b, bool one_triangle) { b.p.store_one_triangle = one_triangle ? 1 : 0; }, "one_triangle"_a);
 
     // DistributedOperator + DefaultApproximationBuilder (distributed_operator/*.hpp)
@@ -669,7 +669,7 @@ PYBIND11_MODULE(Htool, m) {
             check(htool_block_tree_queues(t.owner->root, s.owner->root, &p, target_partition_number, &na, &nd, a.mutable_data(), d.mutable_data()));
             return py::make_tuple(a, d);
         }, "target_cluster"_a, "source_cluster"_a, "eta"_a, "min_target_depth"_a = 0, "min_source_depth"_a = 0, "target_partition_number"_a = -1,
-           "symmetry"_a = 'N', "UPLO"_a = 'N', "one_triangle"_a = false);
+           "symmetry"_a = 'N', "UPLO"_a = 'N', "one_triangle"_a = true);
     m.def("cluster_tiles", [](const PyCluster &c, int partition_number, int tile_max) {
             int n = htool_cluster_tiles(c.owner->root, partition_number, tile_max, nullptr, 0);
             py::array_t<int> out({(py::ssize_t)n, (py::ssize_t)2});

@@ -111,9 +111,10 @@ typedef struct htool_build_params {
     void *compress_ctx;
     htool_dense_blocks_fn dense_blocks; /* NULL: generator */
     void *dense_blocks_ctx;
-    /* 1: a symmetric or Hermitian ('S' / 'H', UPLO 'L'/'U') operator on one cluster tree keeps the UPLO triangle only, like the
-     * reference, and the product applies every stored off-diagonal leaf a second time, (conjugate) transposed.
-     * 0 (default): both triangles are stored and the product is a single plain sweep. */
+    /* 1 (default): a symmetric or Hermitian ('S' / 'H', UPLO 'L'/'U') operator built on one cluster tree without
+     * partition restriction keeps the UPLO triangle only, like the reference, and the product applies
+     * every stored off-diagonal leaf a second time, (conjugate) transposed, in the same pass over its panels.
+     * 0: both triangles are stored and the product is a single plain sweep (faster for many right-hand sides). */
     int store_one_triangle;
 } htool_build_params;
 void htool_build_params_default(htool_build_params *p);

@@ -175,7 +175,7 @@ def test_full_size_configs_by_properties(built, oracle, n, eps, kind, p0, leaf):
 def test_symmetric_operator_is_exactly_symmetric(built, oracle, native):
     """"sym" role rule of the ACA (leaves below the diagonal are compressed through their transpose): for a
     symmetric kernel on one cluster tree the leaves (t,s) and (s,t) carry exactly transposed factors, so the
-    H-matrix is symmetric bit for bit, and the engine (which stores both triangles) agrees to rounding with
+    H-matrix is symmetric bit for bit, and the engine (storing both triangles here) agrees to rounding with
     the oracle's one-triangle storage ('S','L' and 'S','U') that applies stored leaves transposed."""
     import Htool
     from tests.helpers import NumpyGenerator, cluster_of
@@ -187,7 +187,9 @@ def test_symmetric_operator_is_exactly_symmetric(built, oracle, native):
     cl = cluster_of(pts, 16)
     gen = Htool.NativeGenerator("inv_delta", pts, pts, 0.1) if native else NumpyGenerator(pts, pts)
     for sym, uplo in (("N", "N"), ("S", "L"), ("S", "U")):
-        H = Htool.HMatrixTreeBuilder(1e-5, 10.0, sym, uplo).build(gen, cl, cl)
+        builder = Htool.HMatrixTreeBuilder(1e-5, 10.0, sym, uplo)
+        builder.set_symmetric_storage(False)  # both triangles (the default keeps the UPLO triangle only)
+        H = builder.build(gen, cl, cl)
         L = np.asarray(H.leaves())
         index = {tuple(l[:4]): i for i, l in enumerate(L)}
         pairs = [(i, index[(l[2], l[3], l[0], l[1])]) for i, l in enumerate(L) if l[0] > l[2]]
@@ -260,10 +262,7 @@ def test_config_c1_use_hmatrix_10k(built, oracle, kind, p0, symmetry, uplo):
     assert np.linalg.norm(y - OH.matvec(x)) / np.linalg.norm(y_exact) < 1e-5  # ranks may differ by one step on < 1 % of the leaves
     mine = {tuple(l[:4]): int(l[4]) for l in np.asarray(H.leaves())}
     theirs = {tuple(l[:4]): int(l[4]) for l in OH.leaves}
-    if symmetry == "N":
-        assert set(mine) == set(theirs)
-    else:  # the oracle stores one triangle, the engine both: the stored triangle must coincide
-        assert set(theirs) <= set(mine) and all((k[2], k[3], k[0], k[1]) in mine for k in theirs)
+    assert set(mine) == set(theirs)  # 'S','L': the same triangle is stored, leaf for leaf
     diff = np.array([mine[k] - theirs[k] for k in theirs])
     assert np.mean(diff != 0) < 0.01 and np.abs(diff).max() <= 1
     X = np.random.rand(n, 2)

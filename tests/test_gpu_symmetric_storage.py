@@ -1,4 +1,4 @@
-"""GPU parity tests of one-triangle symmetric storage (`HMatrixTreeBuilder.set_symmetric_storage(True)`):
+"""GPU parity tests of one-triangle symmetric storage (the default; `HMatrixTreeBuilder.set_symmetric_storage`):
 symmetry 'S' keeps the UPLO triangle only, as the reference does, and the product uses every
 stored off-diagonal leaf twice in one fused sweep.  Checked against the CPU restatement, which stores the same
 triangle, and against the exact dense kernel.
@@ -139,7 +139,7 @@ def test_one_triangle_callback_generator_copy_and_recompression(built, oracle):
 
 
 def test_one_triangle_falls_back_when_not_eligible(built, oracle):
-    """Rectangular / non-symmetric builds ignore the flag (both triangles stored, a warning is logged)."""
+    """Non-symmetric builds ignore the flag."""
     import Htool
     from tests.helpers import cluster_of
 
@@ -190,3 +190,27 @@ def test_one_triangle_hermitian(built, oracle):
         assert np.abs(D - D.conj().T).max() < 1e-12 * np.abs(D).max()
         results[uplo] = y
     assert np.linalg.norm(results["L"] - results["U"]) / np.linalg.norm(results["L"]) < 2 * eps
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+def test_one_triangle_native_build_recompression(built, oracle, complex_):
+    """Device build (dense leaves and low-rank leaves live in different batches) followed by SVD recompression: the dense
+    batch is left alone and must keep its slots of the coefficient workspace."""
+    import Htool
+
+    O = oracle
+    n, leaf, eps, eta = 6000, 30, 1e-6, 10.0
+    kind, p0 = (2, 4.0) if complex_ else (1, 0.0)
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H, cl, _ = _sym_build(pts, kind, p0, eps, eta, leaf, "L", complex_=complex_)
+    x = np.random.rand(n) + (1j * np.random.rand(n) if complex_ else 0)
+    y_exact = O.dense_matvec(kind, pts, pts, x, p0)
+    assert np.linalg.norm(H * x - y_exact) / np.linalg.norm(y_exact) < eps
+    before = H.stats()["low_rank_elements"]
+    Htool.recompression(H, 1e-3)
+    assert H.stats()["low_rank_elements"] < before
+    e = np.linalg.norm(H * x - y_exact) / np.linalg.norm(y_exact)
+    assert 1e-8 < e < 5e-3
+    H2 = copy.deepcopy(H)
+    assert np.array_equal(H2 * x, H * x)

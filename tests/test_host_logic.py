@@ -285,5 +285,7 @@ def test_block_tree_queues_one_triangle(oracle):
     a, d = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L", one_triangle=True)
     oa, od = O.blocktree(oc, oc, 10.0, "S", "L")
     assert (len(a), len(d)) == (len(oa), len(od))
-    a2, d2 = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L")
-    assert len(a2) > len(a) and len(d2) > len(d)   # default storage keeps both triangles
+    a1, d1 = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L")
+    assert (len(a1), len(d1)) == (len(a), len(d))   # ... which is the default, as in the reference
+    a2, d2 = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L", one_triangle=False)
+    assert len(a2) > len(a) and len(d2) > len(d)    # both triangles on request
