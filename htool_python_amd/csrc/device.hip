@@ -937,6 +937,7 @@ struct DeviceBuilder {
         std::vector<BatchTables> &tabs = D->tabs;
         const long long r_start = (Ns + 1 + 1) / 2 * 2;
         D->W_elems = (r_start + H.r_elems + 2 + 1) / 2 * 2; // even: every right-hand-side copy stays 16-byte aligned
+        HM_CHECK(D->W_elems < (1LL << 31), "coefficient workspace exceeds the 32-bit index range of the panel index arrays");
         HIP_OK(hipMalloc(&D->W, D->W_elems * sizeof(T)));
         HIP_OK(hipMemset(D->W, 0, D->W_elems * sizeof(T)));
         T one;
