@@ -63,6 +63,7 @@ const char *htool_device_name(void) {
     return s.c_str();
 }
 
+int64_t htool_release_workspace(void) { return (int64_t)device_release_workspace(); }
 void htool_set_num_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 
 namespace hm {
@@ -729,15 +730,112 @@ static void require_device() {
     HIP_OK(hipSetDevice(g_device));
 }
 
+static hipError_t dev_malloc(void **p, size_t bytes); // hipMalloc that drops the cached workspace and retries when memory is short
+
 template <typename V>
 static V *upload(const std::vector<V> &h, size_t *bytes = nullptr) {
     V *d = nullptr;
     size_t n = std::max<size_t>(h.size(), 1) * sizeof(V);
-    HIP_OK(hipMalloc((void **)&d, n));
+    HIP_OK(dev_malloc((void **)&d, n));
     if (!h.empty()) HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
     if (bytes) *bytes += n;
     return d;
 }
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------------
+// Large temporary buffers (the ACA arena of a build, its staging buffer, the arena of a recompression or of a bulk
+// download) are kept in a process-wide cache instead of being freed: on this runtime the first allocation after a large
+// hipFree waits until the driver has scrubbed the freed memory (~30 ms per GB: 2.4 s after a 1 M-point build), and
+// build -> recompression -> next build would pay that every time.  The cache holds one buffer per slot; it is dropped
+// by htool_release_workspace(), and automatically when an allocation fails.
+class WorkspaceCache {
+public:
+    enum { ARENA = 0, FLAGS = 1, STAGE = 2, NSLOT = 3 };
+    // a buffer of at least `bytes` on the current device, or nullptr when the slot is in use (concurrent builds): the
+    // caller then allocates privately
+    void *acquire(int slot, size_t bytes) {
+        std::lock_guard<std::mutex> lock(mu_);
+        Slot &s = slots_[slot];
+        if (s.busy) return nullptr;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (s.p && (s.bytes < bytes || s.device != dev)) { (void)hipFree(s.p); s.p = nullptr; s.bytes = 0; }
+        if (!s.p) {
+            const size_t want = std::max<size_t>(bytes, 1);
+            if (hipMalloc(&s.p, want) != hipSuccess) { (void)hipGetLastError(); s.p = nullptr; return nullptr; }
+            s.bytes = want;
+            s.device = dev;
+        }
+        s.busy = true;
+        return s.p;
+    }
+    void give_back(int slot) {
+        std::lock_guard<std::mutex> lock(mu_);
+        slots_[slot].busy = false;
+    }
+    size_t release_all() { // frees what is not in use; returns the bytes freed
+        std::lock_guard<std::mutex> lock(mu_);
+        size_t freed = 0;
+        for (Slot &s : slots_)
+            if (s.p && !s.busy) { (void)hipFree(s.p); freed += s.bytes; s.p = nullptr; s.bytes = 0; }
+        return freed;
+    }
+    size_t slot_bytes(int slot) { // size of the idle buffer cached in a slot (0: none, or in use)
+        std::lock_guard<std::mutex> lock(mu_);
+        return slots_[slot].busy ? 0 : slots_[slot].bytes;
+    }
+    size_t cached_bytes() {
+        std::lock_guard<std::mutex> lock(mu_);
+        size_t b = 0;
+        for (Slot &s : slots_) b += s.bytes;
+        return b;
+    }
+
+private:
+    struct Slot { void *p = nullptr; size_t bytes = 0; int device = -1; bool busy = false; };
+    Slot slots_[NSLOT];
+    std::mutex mu_;
+};
+static WorkspaceCache g_workspace;
+
+size_t device_release_workspace() { return g_workspace.release_all(); }
+size_t device_workspace_bytes() { return g_workspace.cached_bytes(); }
+
+// hipMalloc that gives the cached workspace back to the driver and retries once when memory is short
+static hipError_t dev_malloc(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        (void)hipGetLastError();
+        if (g_workspace.release_all() > 0) e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
+// one leased workspace buffer: from the cache when the slot is free, private otherwise; returned / freed on scope exit
+struct WorkspaceLease {
+    int slot;
+    void *p = nullptr;
+    bool cached = false;
+    explicit WorkspaceLease(int s) : slot(s) {}
+    WorkspaceLease(const WorkspaceLease &) = delete;
+    WorkspaceLease &operator=(const WorkspaceLease &) = delete;
+    void *get(size_t bytes) { // (re)size: the previous content is lost
+        drop();
+        p = g_workspace.acquire(slot, bytes);
+        cached = p != nullptr;
+        if (!p) HIP_OK(dev_malloc(&p, std::max<size_t>(bytes, 1)));
+        return p;
+    }
+    void drop() {
+        if (!p) return;
+        if (cached) g_workspace.give_back(slot);
+        else (void)hipFree(p);
+        p = nullptr;
+    }
+    ~WorkspaceLease() { drop(); }
+};
 
 // scope guard for temporary device buffers (freed on every exit path, exceptions included)
 struct TempPool {
@@ -750,7 +848,7 @@ struct TempPool {
     }
     void *alloc(size_t bytes) {
         void *d = nullptr;
-        HIP_OK(hipMalloc(&d, std::max<size_t>(bytes, 1)));
+        HIP_OK(dev_malloc(&d, std::max<size_t>(bytes, 1)));
         ptrs.push_back(d);
         return d;
     }
@@ -779,6 +877,7 @@ struct DeviceBuilder {
     int *d_rt_off = nullptr, *d_rt_size = nullptr, *d_ct_off = nullptr, *d_ct_size = nullptr;
     DevGen gen{};
     bool have_gen = false;
+    std::vector<void *> deferred_free;
 
     explicit DeviceBuilder(HMatrix &h) : H(h) {
         require_device();
@@ -810,6 +909,7 @@ struct DeviceBuilder {
         d_ct_size = upload(H.ctiles.size);
     }
     ~DeviceBuilder() {
+        for (void *q : deferred_free) (void)hipFree(q);
         (void)hipFree(d_rt_off); (void)hipFree(d_rt_size); (void)hipFree(d_ct_off); (void)hipFree(d_ct_size);
     }
 
@@ -869,9 +969,17 @@ struct DeviceBuilder {
         owned.ptrs.clear(); // success: ownership moves to the device H-matrix
         if (replace_index >= 0) {
             DevBatch &old = D->batches[replace_index];
-            (void)hipFree(old.panelB); (void)hipFree(old.panelA); (void)hipFree(old.cidxB); (void)hipFree(old.oidxA);
-            if (old.zidxB) (void)hipFree(old.zidxB);
-            if (old.tidxA) (void)hipFree(old.tidxA);
+            // With memory to spare the old buffers are released when the builder goes away, i.e. after the tables have
+            // been re-assembled (an allocation issued right after a large free waits for the driver to scrub the freed
+            // memory); when memory is tight they go now.
+            size_t free_now = 0, total_now = 0;
+            HIP_OK(hipMemGetInfo(&free_now, &total_now));
+            const bool defer = free_now > 2 * old.bytes + ((size_t)16 << 30);
+            for (void *q : {old.panelB, old.panelA, (void *)old.cidxB, (void *)old.oidxA, (void *)old.zidxB, (void *)old.tidxA}) {
+                if (!q) continue;
+                if (defer) deferred_free.push_back(q);
+                else (void)hipFree(q);
+            }
             old = B;
             D->tabs[replace_index] = std::move(bt);
         } else {
@@ -938,7 +1046,7 @@ struct DeviceBuilder {
         const long long r_start = (Ns + 1 + 1) / 2 * 2;
         D->W_elems = (r_start + H.r_elems + 2 + 1) / 2 * 2; // even: every right-hand-side copy stays 16-byte aligned
         HM_CHECK(D->W_elems < (1LL << 31), "coefficient workspace exceeds the 32-bit index range of the panel index arrays");
-        HIP_OK(hipMalloc(&D->W, D->W_elems * sizeof(T)));
+        HIP_OK(dev_malloc(&D->W, D->W_elems * sizeof(T)));
         HIP_OK(hipMemset(D->W, 0, D->W_elems * sizeof(T)));
         T one;
         std::memset(&one, 0, sizeof(T));
@@ -957,8 +1065,8 @@ struct DeviceBuilder {
         D->conj_transposed = H.one_triangle && H.is_complex && H.params.symmetry == 'H';
         std::vector<int> ones(maxP, Ns);
         D->ones_idx = upload(ones, &D->table_bytes);
-        HIP_OK(hipMalloc(&D->x_tmp, (size_t)std::max(Ns, 1) * sizeof(T)));
-        HIP_OK(hipMalloc(&D->y_tmp, (size_t)std::max(Tt.n_points, 1) * sizeof(T)));
+        HIP_OK(dev_malloc(&D->x_tmp, (size_t)std::max(Ns, 1) * sizeof(T)));
+        HIP_OK(dev_malloc(&D->y_tmp, (size_t)std::max(Tt.n_points, 1) * sizeof(T)));
 
         std::vector<GSeg> segs;
         std::vector<GTile> tB, tBc, tA, tA2;
@@ -1080,7 +1188,7 @@ struct DeviceBuilder {
         if (D->splitB > 1) {
             const int S = D->splitB;
             D->ypart_stride = ((long long)H.row_size + 1) / 2 * 2;
-            HIP_OK(hipMalloc(&D->ypart, (size_t)S * D->ypart_stride * sizeof(T)));
+            HIP_OK(dev_malloc(&D->ypart, (size_t)S * D->ypart_stride * sizeof(T)));
             D->table_bytes += (size_t)S * D->ypart_stride * sizeof(T);
             for (int r = 0; r < nrt; r++) {
                 const GTile &t0 = tBc[r];
@@ -1191,7 +1299,7 @@ struct DeviceBuilder {
             D->zd_woff = upload(zw, &D->table_bytes);
             D->zd_rows = upload(rows, &D->table_bytes);
             D->n_zd_tiles = nrt;
-            HIP_OK(hipMalloc(&D->ycl, (size_t)std::max(Tt.n_points, 1) * sizeof(T)));
+            HIP_OK(dev_malloc(&D->ycl, (size_t)std::max(Tt.n_points, 1) * sizeof(T)));
             D->table_bytes += (size_t)Tt.n_points * sizeof(T);
         }
         D->segs = upload(segs, &D->table_bytes);
@@ -1210,7 +1318,7 @@ void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems) 
     DeviceBuilder db(H);
     size_t es = H.is_complex ? 16 : 8;
     void *d_arena = nullptr;
-    HIP_OK(hipMalloc(&d_arena, std::max<int64_t>(arena_elems, 1) * es));
+    HIP_OK(dev_malloc(&d_arena, std::max<int64_t>(arena_elems, 1) * es));
     if (arena_elems) HIP_OK(hipMemcpy(d_arena, arena, arena_elems * es, hipMemcpyHostToDevice));
     std::vector<int64_t> all;
     for (size_t i = 0; i < H.blocks.size(); i++) if (H.blocks[i].rank != 0) all.push_back((int64_t)i);
@@ -1277,7 +1385,7 @@ template <typename T>
 static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     if (nr <= D->rhs_cap) return;
     void *nW = nullptr;
-    HIP_OK(hipMalloc(&nW, (size_t)nr * D->W_elems * sizeof(T)));
+    HIP_OK(dev_malloc(&nW, (size_t)nr * D->W_elems * sizeof(T)));
     HIP_OK(hipMemset(nW, 0, (size_t)nr * D->W_elems * sizeof(T)));
     T one;
     std::memset(&one, 0, sizeof(T));
@@ -1298,7 +1406,7 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     D->W = nW;
     if (D->splitB > 1) {
         if (D->ypart) (void)hipFree(D->ypart);
-        HIP_OK(hipMalloc(&D->ypart, (size_t)nr * D->splitB * D->ypart_stride * sizeof(T)));
+        HIP_OK(dev_malloc(&D->ypart, (size_t)nr * D->splitB * D->ypart_stride * sizeof(T)));
     }
     D->rhs_cap = nr;
 }
@@ -1369,8 +1477,8 @@ void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
     const bool whole = H.t_root == 0;
     const size_t nin = (size_t)D->n_source, nout = (size_t)(whole ? D->n_target : D->row_size);
     void *dX = nullptr, *dY = nullptr;
-    HIP_OK(hipMalloc(&dX, std::max<size_t>(nin * mu, 1) * es));
-    HIP_OK(hipMalloc(&dY, std::max<size_t>(nout * mu, 1) * es));
+    HIP_OK(dev_malloc(&dX, std::max<size_t>(nin * mu, 1) * es));
+    HIP_OK(dev_malloc(&dY, std::max<size_t>(nout * mu, 1) * es));
     HIP_OK(hipMemcpyAsync(dX, X, nin * mu * es, hipMemcpyHostToDevice, D->stream));
     device_matmat_device(H, dX, (long long)nin, dY, (long long)nout, mu, host_numbering(H), D->stream);
     HIP_OK(hipMemcpyAsync(Y, dY, nout * mu * es, hipMemcpyDeviceToHost, D->stream));
@@ -1451,7 +1559,7 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     for (auto &slot : D->pev) for (auto &e : slot) { e = nullptr; HIP_OK(hipEventCreate(&e)); }
     auto dup = [](const void *p, size_t bytes) -> void * {
         void *q = nullptr;
-        HIP_OK(hipMalloc(&q, std::max<size_t>(bytes, 1)));
+        HIP_OK(dev_malloc(&q, std::max<size_t>(bytes, 1)));
         if (p && bytes) HIP_OK(hipMemcpy(q, p, bytes, hipMemcpyDeviceToDevice));
         return q;
     };

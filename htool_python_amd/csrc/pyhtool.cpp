@@ -670,6 +670,7 @@ PYBIND11_MODULE(Htool, m) {
             return py::make_tuple(a, d);
         }, "target_cluster"_a, "source_cluster"_a, "eta"_a, "min_target_depth"_a = 0, "min_source_depth"_a = 0, "target_partition_number"_a = -1,
            "symmetry"_a = 'N', "UPLO"_a = 'N', "one_triangle"_a = true);
+    m.def("release_workspace", []() { return htool_release_workspace(); }, "Free the cached temporary device buffers of builds / recompressions; returns the bytes released");
     m.def("cluster_tiles", [](const PyCluster &c, int partition_number, int tile_max) {
             int n = htool_cluster_tiles(c.owner->root, partition_number, tile_max, nullptr, 0);
             py::array_t<int> out({(py::ssize_t)n, (py::ssize_t)2});

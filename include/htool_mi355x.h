@@ -41,6 +41,11 @@ int htool_device_count(void);          /* number of usable HIP devices (0 on a G
 int htool_set_device(int device);      /* select the HIP device for objects created afterwards */
 const char *htool_device_name(void);   /* e.g. "gfx950:..." or "" */
 void htool_set_num_threads(int n);     /* OpenMP threads of the host-side tree construction (0: leave as is) */
+/* Builds and recompressions keep their large temporary device buffers (the ACA arena ...) in a process-wide cache for
+ * the next call instead of freeing them (a large hipFree makes the next allocation wait for the driver to scrub the
+ * memory).  This gives the cache back to the driver; returns the number of bytes released.  The library does it by
+ * itself when one of its allocations fails. */
+int64_t htool_release_workspace(void);
 
 /* replaces PythonLoggerWriter / htool::Logger (misc/logger.hpp:10-37, main.cpp:42).
  * levels: 0 CRITICAL, 1 ERROR, 2 WARNING, 3 DEBUG, 4 INFO (order of logger.hpp:17-32) */

@@ -1,0 +1,18 @@
+import logging, time, sys
+logging.basicConfig(level=logging.DEBUG, stream=sys.stderr)
+import numpy as np, torch, Htool
+from htool_python_amd.workloads import points_in_sphere
+n = 1_000_000
+leaf = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+pts = points_in_sphere(n, seed=0)
+Htool.set_num_threads(16)
+cb = Htool.ClusterTreeBuilder(); cb.set_maximal_leaf_size(leaf)
+cl = cb.create_cluster_tree(pts, 2)
+gen = Htool.NativeGenerator("laplace", pts, pts, 0.0)
+t0 = time.time()
+H = Htool.HMatrixTreeBuilder(1e-3, 10.0, "N", "N").build(gen, cl, cl)
+torch.cuda.synchronize(); t1 = time.time()
+print(f"build {t1-t0:.3f}", file=sys.stderr)
+Htool.recompression(H)
+torch.cuda.synchronize(); t2 = time.time()
+print(f"recompress {t2-t1:.3f}", file=sys.stderr)

@@ -406,3 +406,51 @@ def test_multi_round_build_with_held_factors(built, oracle, monkeypatch, arena_m
     assert np.linalg.norm(y1 - y2) / np.linalg.norm(y1) < 1e-13
     y_exact = O.dense_matvec(1, pts, pts, x, 0.0)
     assert np.linalg.norm(y2 - y_exact) / np.linalg.norm(y_exact) < eps
+
+
+def test_recompression_in_chunks(built, oracle, monkeypatch):
+    """A small recompression arena splits a batch into several chunks (each becomes a batch of its own): same ranks and
+    same operator as the single-chunk pass."""
+    import Htool
+
+    O = oracle
+    n, leaf, eps, eta = 8000, 32, 1e-6, 10.0
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    H1, _, _ = _build(pts, pts, 1, 0.0, eps, eta, leaf)
+    H2, _, _ = _build(pts, pts, 1, 0.0, eps, eta, leaf)
+    Htool.recompression(H1, 1e-3)
+    monkeypatch.setenv("HTOOL_RECOMPRESS_ARENA_MB", "3")
+    Htool.recompression(H2, 1e-3)
+    monkeypatch.delenv("HTOOL_RECOMPRESS_ARENA_MB")
+    r1 = {tuple(l[:4]): int(l[4]) for l in np.asarray(H1.leaves())}
+    r2 = {tuple(l[:4]): int(l[4]) for l in np.asarray(H2.leaves())}
+    assert r1 == r2
+    x = np.random.rand(n)
+    y1, y2 = H1 * x, H2 * x
+    assert np.linalg.norm(y1 - y2) / np.linalg.norm(y1) < 1e-13
+    y_exact = O.dense_matvec(1, pts, pts, x, 0.0)
+    assert 1e-8 < np.linalg.norm(y2 - y_exact) / np.linalg.norm(y_exact) < 5e-3
+    assert np.array_equal((H2 @ np.asfortranarray(x[:, None]))[:, 0], y2)
+
+
+def test_workspace_cache_is_reused_and_released(built, oracle):
+    """Builds keep their temporary arena in a process-wide cache (a large hipFree would make the next allocation wait
+    for the driver to scrub it); `Htool.release_workspace()` hands it back."""
+    import Htool
+
+    O = oracle
+    np.random.seed(0)
+    pts = O.points_in_sphere(5000)
+    Htool.release_workspace()
+    H1, _, _ = _build(pts, pts, 1, 0.0, 1e-4, 10.0, 32)
+    x = np.random.rand(5000)
+    y1 = H1 * x
+    H2, _, _ = _build(pts, pts, 1, 0.0, 1e-4, 10.0, 32)   # second build runs in the cached arena
+    assert np.array_equal(H2 * x, y1)
+    Htool.recompression(H2, 1e-2)
+    freed = Htool.release_workspace()
+    assert freed > 0
+    assert Htool.release_workspace() == 0
+    H3, _, _ = _build(pts, pts, 1, 0.0, 1e-4, 10.0, 32)
+    assert np.array_equal(H3 * x, y1)
