@@ -447,7 +447,9 @@ __global__ __launch_bounds__(256) void tile_gemv_tall_transposed(const GTile *__
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row0 = lane * Ops::RPL;
     const int cs = tl.nrows; // source positions of the tile = columns of its panels
-    const int j0 = wave * CG;
+    // narrow tiles (at most half the maximal tile) give every wave 16 columns instead of 32 / 16, so that all four work
+    const int cgw = (cs <= TM / 2 && CG > 16) ? CG / 2 : CG;
+    const int j0 = wave * cgw;
     if (j0 >= cs) return;
     T acc[CG];
 #pragma unroll
@@ -475,25 +477,29 @@ __global__ __launch_bounds__(256) void tile_gemv_tall_transposed(const GTile *__
             const T *base = (const T *)sg.panel + (long long)q * sg.chunk_stride + row0 + (long long)j0 * ld;
 #pragma unroll
             for (int cc = 0; cc < CG; cc += 16) {
-                double2 v[16];
+                if (cc < cgw) {
+                    double2 v[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++) v[u] = (active && j0 + cc + u < cs) ? ldnt16(base + (long long)(cc + u) * ld) : make_double2(0.0, 0.0);
+                    for (int u = 0; u < 16; u++) v[u] = (active && j0 + cc + u < cs) ? ldnt16(base + (long long)(cc + u) * ld) : make_double2(0.0, 0.0);
 #pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    if (Ops::RPL == 2 && !second) v[u].y = 0.0; // the padding row of an odd last chunk is never written
-                    if (Ops::RPL == 1 && conj_t) v[u].y = -v[u].y;
-                    Ops::tacc(acc[cc + u], v[u], z);
+                    for (int u = 0; u < 16; u++) {
+                        if (Ops::RPL == 2 && !second) v[u].y = 0.0; // the padding row of an odd last chunk is never written
+                        if (Ops::RPL == 1 && conj_t) v[u].y = -v[u].y;
+                        Ops::tacc(acc[cc + u], v[u], z);
+                    }
                 }
             }
         }
     }
 #pragma unroll
     for (int cc = 0; cc < CG; cc += 16) {
-        lane_transpose_reduce16<Ops>(acc + cc, lane);
-        const int j = j0 + cc + (lane >> 2);
-        if ((lane & 3) == 0 && j < cs) {
-            T *o = ycl + tl.out_begin + j;
-            *o = Ops::add(*o, acc[cc]);
+        if (cc < cgw) {
+            lane_transpose_reduce16<Ops>(acc + cc, lane);
+            const int j = j0 + cc + (lane >> 2);
+            if ((lane & 3) == 0 && j < j0 + cgw && j < cs) {
+                T *o = ycl + tl.out_begin + j;
+                *o = Ops::add(*o, acc[cc]);
+            }
         }
     }
 }
@@ -1184,7 +1190,6 @@ struct DeviceBuilder {
         std::vector<GTile> tBs;
         std::vector<double> wBs;
         D->splitB = std::max(1, std::min(8, (target_items + std::max(nrt, 1) - 1) / std::max(nrt, 1)));
-        if (H.one_triangle) D->splitB = 1; // the fused sweep writes whole rows of the cluster-numbered accumulator
         if (D->splitB > 1) {
             const int S = D->splitB;
             D->ypart_stride = ((long long)H.row_size + 1) / 2 * 2;
@@ -1212,6 +1217,7 @@ struct DeviceBuilder {
                             GSeg sp = sg;
                             sp.panel = (const char *)sg.panel + (size_t)(a - pos) * (size_t)sg.ld_last * sizeof(T);
                             sp.cidx = sg.cidx + (a - pos);
+                            if (sg.zidx) sp.zidx = sg.zidx + (a - pos);
                             sp.ncols = (int)(bnd - a);
                             segs.push_back(sp);
                             t.nseg++;
@@ -1359,7 +1365,13 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
         // use of the V panels, then the transposed dense results and the scatter to the caller's numbering
         if constexpr (NR == 1) {
             T *ycl = (T *)D->ycl;
-            if (D->nB) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const T *)W, W, ycl, D->conj_transposed ? 1 : 0);
+            if (D->splitB > 1 && D->nB_split) { // small operator: column slices of the row tiles, summed in slice order
+                hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, W, (T *)D->ypart, D->conj_transposed ? 1 : 0);
+                hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
+                                   (const int *)nullptr, ycl, 0LL, 1);
+            } else if (D->nB) {
+                hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const T *)W, W, ycl, D->conj_transposed ? 1 : 0);
+            }
             if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, 1>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, 0LL);
             if (D->nAT) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, D->conj_transposed ? 1 : 0);
             if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym_kernel<T>, dim3(D->n_zd_tiles), dim3(128), 0, st, (const T *)ycl, (const T *)W, D->zd_ptr, D->zd_woff, D->zd_rows,
