@@ -331,3 +331,17 @@ def test_local_blocks_partition_by_partition(built, oracle):
     y[perm] = yp
     ye = O.dense_matvec(O.K_LAPLACE, pts, pts, x)
     assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < eps
+
+
+def test_degenerate_inputs_sweep(built):
+    """243 builds on degenerate inputs (1, 2, 7 points; identical, duplicated, collinear points; 2-D; leaf size 1 and
+    leaf size > N; 'N' / 'S','L' / 'S','U'; the three native kernels): every one must build, multiply without NaN and
+    match the exact dense operator (tools/edge_sweep.py)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "edge_sweep.py")
+    spec = importlib.util.spec_from_file_location("edge_sweep", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(verbose=False) == []
