@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace hm {
 
@@ -27,5 +28,12 @@ struct Error : std::runtime_error {
 std::string strprintf(const char *fmt, ...);
 
 double wall_seconds();
+
+// OpenMP loop for translation units that are not compiled with OpenMP (the .hip file): fn(i, ctx) for i in [0, n)
+void parallel_for_index(long long n, void (*fn)(long long, void *), void *ctx);
+template <typename F>
+inline void parallel_for(long long n, F &&f) {
+    parallel_for_index(n, [](long long i, void *c) { (*static_cast<typename std::remove_reference<F>::type *>(c))(i); }, (void *)&f);
+}
 
 } // namespace hm

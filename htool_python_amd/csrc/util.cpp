@@ -28,6 +28,11 @@ std::string strprintf(const char *fmt, ...) {
     return std::string(buf.data(), (size_t)n);
 }
 
+void parallel_for_index(long long n, void (*fn)(long long, void *), void *ctx) {
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < n; i++) fn(i, ctx);
+}
+
 double wall_seconds() {
     using namespace std::chrono;
     return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
