@@ -24,6 +24,7 @@ from htool_python_amd.distributed import (  # noqa: F401,E402
     VirtualLocalToLocalOperator,
 )
 
+ComplexDDMSolverBuilder = DDMSolverBuilder
 ComplexDefaultApproximationBuilder = DefaultApproximationBuilder
 ComplexDefaultLocalApproximationBuilder = DefaultLocalApproximationBuilder
 ComplexDistributedOperator = DistributedOperator

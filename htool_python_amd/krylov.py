@@ -13,9 +13,10 @@ import numpy as np
 import torch
 
 
-def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, callback=None):
+def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, callback=None, precond=None):
     """Solve A x = b.  `apply(v)` returns A v for a device tensor v (this rank's slice); `reduce(t)` sums
-    the small device tensor t over the ranks in place (None for one rank).  Returns (x, info);
+    the small device tensor t over the ranks in place (None for one rank); `precond(v)` applies M^-1 to this
+    rank's slice (right preconditioning: A M^-1 u = b, x = M^-1 u; `-hpddm_variant right`).  Returns (x, info);
     info["residuals"][k] is the relative residual |b - A x_k| / |b| given by the Arnoldi recurrence."""
     dev, dt = b.device, b.dtype
     n = b.numel()
@@ -50,7 +51,7 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
         Hh = np.zeros((m + 1, m), dtype=npdt)
         y, k = None, 0
         for j in range(m):
-            w = apply(V[j])
+            w = apply(V[j] if precond is None else precond(V[j]))
             Vj = V[: j + 1]
             h = allsum(torch.mv(Vj.conj(), w))
             w = w - torch.mv(Vj.t(), h)
@@ -72,7 +73,8 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
                 callback(info["iterations"], res)
             if res <= tol or info["iterations"] >= max_it or hn == 0:
                 break
-        x = x + torch.mv(V[:k].t(), torch.from_numpy(y).to(device=dev, dtype=dt))
+        dx = torch.mv(V[:k].t(), torch.from_numpy(y).to(device=dev, dtype=dt))
+        x = x + (dx if precond is None else precond(dx))
         info["restarts"] += 1
         if info["residuals"][-1] <= tol:
             info["converged"] = True

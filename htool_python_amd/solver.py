@@ -7,8 +7,11 @@ example/use_ddm_solver.py:49-69).  The reference delegates to HPDDM (absent); he
 package's own restarted GMRES on GPU-resident vectors (krylov.py) with the H-matrix product as operator.
 Only the options the reference's tests use are parsed (tests/test_ddm_solver.py:550-558):
 -hpddm_krylov_method gmres, -hpddm_tol, -hpddm_max_it, -hpddm_gmres_restart, -hpddm_variant right.
-No preconditioner is applied (block-Jacobi/Schwarz/GenEO are out of scope):
-`facto_one_level()` is a no-op and the `block_diagonal_hmatrix` argument is ignored.
+`facto_one_level()` sets up a block-Jacobi preconditioner from the DENSE DIAGONAL LEAVES of this rank's H-matrix
+("Block-Jacobi via dense LU of small diagonal blocks"): the leaves (t, t) of the cluster-tree leaves tile
+the diagonal; they are downloaded once, LU-factorised as one padded batch (library call) and applied as a right
+preconditioner.  The reference's one-level Schwarz with an H-LU of the whole local block, and GenEO, are out of scope
+(SURVEY.md 2.1 row 12); the `block_diagonal_hmatrix` argument is accepted and ignored.
 """
 import time
 
@@ -73,6 +76,40 @@ class DeviceOperator:
         return t
 
 
+class BlockJacobi:
+    """M^-1 = blockdiag(D_1, ..., D_q)^-1 with D_i the dense diagonal leaves (+ shift I) of the local rows."""
+
+    def __init__(self, hmatrix, offset, size, shift=0.0):
+        leaves = np.asarray(hmatrix.leaves())
+        ids = [i for i, l in enumerate(leaves) if l[4] < 0 and l[0] == l[2] and l[1] == l[3] and offset <= l[0] < offset + size]
+        ids.sort(key=lambda i: leaves[i][0])
+        cover = sum(int(leaves[i][1]) for i in ids)
+        if cover != size:
+            raise RuntimeError(f"block-Jacobi: the dense diagonal leaves cover {cover} of {size} local rows")
+        offs, data = hmatrix.leaf_panels_bulk(np.asarray(ids, dtype=np.int64))
+        data = np.asarray(data)
+        sizes = [int(leaves[i][1]) for i in ids]
+        bmax = max(sizes)
+        blocks = np.zeros((len(ids), bmax, bmax), dtype=data.dtype)
+        index = np.empty(size, dtype=np.int64)
+        for q, i in enumerate(ids):
+            m = sizes[q]
+            blocks[q, :m, :m] = data[offs[q, 0]: offs[q, 0] + m * m].reshape(m, m).T  # column-major block
+            blocks[q, np.arange(m), np.arange(m)] += shift
+            blocks[q, np.arange(m, bmax), np.arange(m, bmax)] = 1.0                  # padding: identity
+            o = int(leaves[i][0]) - offset
+            index[o: o + m] = q * bmax + np.arange(m)
+        self.index = torch.from_numpy(index).cuda()
+        self.lu, self.piv = torch.linalg.lu_factor(torch.from_numpy(blocks).cuda())
+        self.nb, self.bmax = len(ids), bmax
+
+    def __call__(self, v):
+        pad = torch.zeros(self.nb * self.bmax, dtype=v.dtype, device=v.device)
+        pad[self.index] = v
+        sol = torch.linalg.lu_solve(self.lu, self.piv, pad.view(self.nb, self.bmax, 1))
+        return sol.reshape(-1)[self.index]
+
+
 class Solver:
     def __init__(self, distributed_operator=None, hmatrix=None, shift=0.0):
         from .krylov import gmres
@@ -80,6 +117,7 @@ class Solver:
         self._gmres = gmres
         self._opts = {"tol": 1e-6, "max_it": 200, "restart": 50}
         self._info = {}
+        self._precond = None
         if distributed_operator is not None:
             H = distributed_operator.local_hmatrix
             comm = distributed_operator.comm
@@ -95,7 +133,8 @@ class Solver:
         self._perm = np.asarray(self.op.H.get_source_cluster().get_permutation())
 
     def facto_one_level(self):
-        """No preconditioner (see module docstring)."""
+        """Block-Jacobi on the dense diagonal leaves of the local rows (see module docstring)."""
+        self._precond = BlockJacobi(self.op.H, self.op.offset, self.op.size, self.op.shift)
 
     def build_coarse_space(self, *a, **k):
         raise RuntimeError("GenEO coarse spaces are outside the MI355X hot path; not implemented")
@@ -117,7 +156,8 @@ class Solver:
             x0 = None
             if np.any(np.asarray(xc) != 0):
                 x0 = torch.from_numpy(np.ascontiguousarray(np.asarray(xc)[self._perm][off:off + size])).cuda()
-            xl, info = self._gmres(self.op.apply, bl, x0, self._opts["tol"], self._opts["restart"], self._opts["max_it"], self.op.reduce if self.op.world > 1 else None)
+            xl, info = self._gmres(self.op.apply, bl, x0, self._opts["tol"], self._opts["restart"], self._opts["max_it"], self.op.reduce if self.op.world > 1 else None,
+                                   precond=self._precond)
             full = self._gather(xl)
             out = np.empty_like(full)
             out[self._perm] = full
@@ -126,7 +166,8 @@ class Solver:
             res.append(info["residuals"][-1] if info["residuals"] else 0.0)
             self._history = info["residuals"]
         self._info = {"Nb_it": str(max(its)), "Relative_residual": str(max(res)), "Solve_seconds": str(time.time() - t0),
-                      "Products": str(self.op.products), "Krylov_method": "gmres", "Preconditioner": "none"}
+                      "Products": str(self.op.products), "Krylov_method": "gmres",
+                      "Preconditioner": "none" if self._precond is None else "block-jacobi (dense diagonal leaves)"}
 
     def _gather(self, xl):
         if self.op.world == 1:
