@@ -642,7 +642,9 @@ PYBIND11_MODULE(Htool, m) {
         .def("create_cluster_tree", [](CB &self, CB::coords_t coordinates, int number_of_children, std::optional<int> size_of_partition, std::optional<CB::coords_t> radii,
                                        std::optional<CB::coords_t> weights) {
                 return self.create(coordinates, number_of_children, size_of_partition ? *size_of_partition : number_of_children, nullptr, false, radii, weights);
-            }, "coordinates"_a, "number_of_children"_a, py::kw_only(), "size_of_partition"_a = py::none(), "radii"_a = py::none(), "weights"_a = py::none())
+            // the reference binding makes size_of_partition keyword-only (cluster_tree_builder.hpp:28-31) while its own
+            // example passes it positionally (example/use_ddm_solver.py:30-32): both spellings are accepted here
+            }, "coordinates"_a, "number_of_children"_a, "size_of_partition"_a = py::none(), py::kw_only(), "radii"_a = py::none(), "weights"_a = py::none())
         .def("create_cluster_tree_from_global_partition", [](CB &self, CB::coords_t coordinates, int number_of_children, int size_of_partition, CB::part_t partition,
                                                              std::optional<CB::coords_t> radii, std::optional<CB::coords_t> weights) {
                 if (partition.ndim() != 1 || partition.shape(0) != coordinates.shape(1)) throw std::runtime_error("Wrong format for partition");

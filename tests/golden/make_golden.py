@@ -17,6 +17,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True  # the reference tree is read-only for this project: no __pycache__ there
 sys.path.insert(0, "/root/reference")
 from example.create_geometry import create_partitionned_geometries, create_random_geometries  # noqa: E402
 
