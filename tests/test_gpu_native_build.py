@@ -454,3 +454,41 @@ def test_workspace_cache_is_reused_and_released(built, oracle):
     assert Htool.release_workspace() == 0
     H3, _, _ = _build(pts, pts, 1, 0.0, 1e-4, 10.0, 32)
     assert np.array_equal(H3 * x, y1)
+
+
+def test_no_device_memory_leak(built, oracle):
+    """build / multiply / multi-RHS / deep copy / recompress / destroy, both storages, in a loop: once the workspace
+    cache is released the free device memory is back where it was (tools/leak_check.py does the same at 300 000 points)."""
+    import copy
+    import gc
+
+    import torch
+
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    n = 20000
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 50)
+    x = np.random.rand(n)
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    marks = []
+    for _ in range(3):
+        for sym, uplo in (("N", "N"), ("S", "L")):
+            H = Htool.HMatrixTreeBuilder(1e-4, 10.0, sym, uplo).build(Htool.NativeGenerator("laplace", pts, pts, 0.0), cl, cl)
+            H * x
+            H @ np.asfortranarray(np.random.rand(n, 3))
+            H2 = copy.deepcopy(H)
+            Htool.recompression(H2, 1e-2)
+            H2 * x
+            del H, H2
+            gc.collect()
+        Htool.release_workspace()
+        marks.append(free_bytes())
+    assert abs(marks[-1] - marks[0]) < 32 << 20, marks
