@@ -11,6 +11,13 @@
 // wave instruction), 16 loads in flight per wave; coefficients are fetched once per 16/64 columns
 // and broadcast with v_readlane; sums are formed in a fixed order (no atomics), so the product is
 // bitwise reproducible.
+// A symmetric / Hermitian operator stored as one triangle (the reference's 'S' / 'H' storage) is multiplied
+// by a fused variant that uses every stored off-diagonal leaf as A and as A^T in one pass over its panels:
+//   gather_x -> tile_gemv_tall -> A2 -> tile_gemv_wide_sym (y and the transposed dot products z = U^T x)
+//            -> sums of the z partials -> tile_gemv_tall_transposed (y += V^T z) -> finish_sym
+// Also here: the pack kernels (per-leaf factors -> tile panels), the device-memory helpers (workspace
+// cache of the large temporary buffers), the table assembly and the host drivers.  The device ACA and the
+// native build live in device_build.inc, the SVD recompression in device_recompress.inc.
 #include "device_internal.hpp"
 
 #include <algorithm>
