@@ -213,6 +213,7 @@ def main():
         Htool.recompression(H)
         torch.cuda.synchronize()
         t_recompress = time.time() - t0
+    H.set_phase_timing(True)  # HIP events around every launch of a product (the roofline object needs them)
     leaves = H.leaves()
     n_rows = H.shape[0]
     ab = algorithmic_bytes(leaves, n, n_rows, elem)

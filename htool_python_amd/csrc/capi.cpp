@@ -574,6 +574,11 @@ void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8) {
 }
 double htool_hmatrix_last_product_us(const htool_hmatrix *h) { return device_last_product_us(h->H); }
 int htool_hmatrix_phase_times(const htool_hmatrix *h, double *out4) { return device_phase_times(h->H, out4); }
+int htool_hmatrix_set_phase_timing(htool_hmatrix *h, int on) {
+    API_BEGIN
+    device_set_phase_timing(h->H, on != 0);
+    API_END
+}
 
 int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap) {
     const HMatrix &H = h->H;

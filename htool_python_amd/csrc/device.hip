@@ -1352,13 +1352,14 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     // numbering: 0 user in / user out, 1 cluster / cluster, 2 user / cluster, 3 cluster / user
     const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
     hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
-    HIP_OK(hipEventRecord(ev[0], st));
+    const bool timing = D->phase_timing; // five event records cost ~19 us per product: off unless asked for
+    if (timing) HIP_OK(hipEventRecord(ev[0], st));
     if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, x_stride, in_user ? D->perm_s : (const int *)nullptr, W, ws, Ns, NR);
-    HIP_OK(hipEventRecord(ev[1], st));
+    if (timing) HIP_OK(hipEventRecord(ev[1], st));
     if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W, ws, ws, 0LL);
-    HIP_OK(hipEventRecord(ev[2], st));
+    if (timing) HIP_OK(hipEventRecord(ev[2], st));
     if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W, ws, ws, ws);
-    HIP_OK(hipEventRecord(ev[3], st));
+    if (timing) HIP_OK(hipEventRecord(ev[3], st));
     auto launch_wide = [&](const GTile *tiles, const int *cnt, T *out, long long out_stride) {
         const GTile *t = tiles;
         if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 1>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
@@ -1394,9 +1395,9 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     } else if (D->nB) {
         launch_wide(out_user ? D->tilesB_user : D->tilesB_cluster, D->cntB, (T *)y_dev, y_stride);
     }
-    HIP_OK(hipEventRecord(ev[4], st));
+    if (timing) HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
-    D->nprod++;
+    if (timing) D->nprod++;
 }
 
 // make room for nr coefficient workspaces (and partial-y slabs); W[r][n_source] = 1 for every r
@@ -1504,6 +1505,11 @@ void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
     HIP_OK(hipStreamSynchronize(D->stream));
     (void)hipFree(dX);
     (void)hipFree(dY);
+}
+
+void device_set_phase_timing(const HMatrix &H, bool on) {
+    HM_CHECK(H.dev != nullptr, "H-matrix has no device data");
+    H.dev->phase_timing = on;
 }
 
 // average duration (microseconds) of the four launches over the completed products still in the ring:

@@ -70,6 +70,7 @@ struct DeviceHMatrix {
     // write partial sums to ypart[slice][row] and reduce_y_kernel adds them in slice order
     int splitB = 1, nB_split = 0;
     // one-triangle storage of a symmetric operator: extra tables and a cluster-numbered accumulator for y
+    bool phase_timing = false;      // record the per-phase events of every product (htool_hmatrix_set_phase_timing)
     bool one_triangle = false;
     bool conj_transposed = false;   // 'H': the second use of a stored leaf is its conjugate transpose
     GTile *tilesAT = nullptr, *tilesZ = nullptr; // transposed use of the tall panels; sums of the transposed partials

@@ -160,6 +160,7 @@ int64_t device_leaf_panels_bulk(const HMatrix &H, int64_t n, const int64_t *ids,
 int64_t device_resident_bytes(const HMatrix &H);
 double device_last_product_us(const HMatrix &H);
 int device_phase_times(const HMatrix &H, double *out4);
+void device_set_phase_timing(const HMatrix &H, bool on);
 void device_free(DeviceHMatrix *d);
 size_t device_release_workspace(); // frees the cached temporary buffers (build arena ...); returns the bytes freed
 size_t device_workspace_bytes();

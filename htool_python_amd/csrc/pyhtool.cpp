@@ -508,6 +508,7 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 d["sum_rank"] = st[4]; d["hbm_bytes"] = st[5]; d["build_seconds"] = st[6] * 1e-6; d["max_rank"] = st[7];
                 return d;
             })
+        .def("set_phase_timing", [](const H &s, bool on) { check(htool_hmatrix_set_phase_timing(s.h, on ? 1 : 0)); }, "on"_a = true)
         .def("last_product_us", [](const H &s) { return htool_hmatrix_last_product_us(s.h); })
         .def("phase_times_us", [](const H &s) {
                 double t[4];

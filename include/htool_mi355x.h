@@ -204,6 +204,10 @@ int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap);
  * elements sum r(m+n), out[2]=n dense leaves, out[3]=n low-rank leaves, out[4]=sum of ranks,
  * out[5]=bytes resident in HBM, out[6]=build seconds*1e6, out[7]=max rank */
 void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8);
+/* Per-phase timing of the products of this handle (HIP events around every launch, recorded on the stream the kernels
+ * run on).  Off by default: the five event records cost about 19 us per product, a quarter of the time of a
+ * 10 000-point product.  The two queries below report nothing while it is off. */
+int htool_hmatrix_set_phase_timing(htool_hmatrix *h, int on);
 /* time of the kernels of the last product in microseconds (HIP events), -1 if none */
 double htool_hmatrix_last_product_us(const htool_hmatrix *h);
 /* average duration in microseconds of the four launches of a product (HIP events recorded on the

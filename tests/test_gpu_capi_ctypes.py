@@ -63,6 +63,9 @@ def test_c_abi_end_to_end(built, oracle):
     d = leaves[:, 4] < 0
     assert st[0] == (leaves[d, 1].astype(np.int64) * leaves[d, 3]).sum() and st[2] == d.sum() and st[5] > 8 * (st[0] + st[1])
     times = (ctypes.c_double * 4)()
+    assert L.htool_hmatrix_phase_times(H, times) == 0          # per-phase events are off by default
+    assert L.htool_hmatrix_set_phase_timing(H, 1) == 0
+    assert L.htool_hmatrix_matvec(H, ctypes.c_char(b"N"), None, x.ctypes, None, y2.ctypes) == 0
     assert L.htool_hmatrix_phase_times(H, times) >= 1 and times[3] > 0
     # errors: transposed products are not implemented; the message is retrievable
     assert L.htool_hmatrix_matvec(H, ctypes.c_char(b"T"), None, x.ctypes, None, y.ctypes) != 0
