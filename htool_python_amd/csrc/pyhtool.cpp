@@ -566,7 +566,11 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("set_dense_blocks_generator", [](B &b, py::object g) { b.dense_blocks = g.cast<std::shared_ptr<PyVirtualDenseBlocksGenerator<T>>>(); b.dense_blocks_ref = g; })
         .def("set_block_tree_consistency", [](B &b, bool c) { b.p.block_tree_consistency = c ? 1 : 0; })
         // extension: False stores both triangles of a symmetric operator (default: the UPLO triangle only, as the reference does)
-        .def("set_symmetric_storage", [](B &b, bool one_triangle) { b.p.store_one_triangle = one_triangle ? 1 : 0; }, "one_triangle"_a);
+        .def("set_symmetric_storage", [](B &b, bool one_triangle) { b.p.store_one_triangle = one_triangle ? 1 : 0; }, "one_triangle"_a,
+             "True (default): symmetry 'S'/'H' keeps the UPLO triangle only, as the reference does; every product uses each stored leaf "
+             "twice in one fused sweep (half the memory, about 1.5x faster per vector above ~20 000 unknowns).  False: both triangles "
+             "are stored; preferable when products mostly come with many right-hand sides (H @ X sweeps 8 columns per pass then, "
+             "one column per pass in one-triangle storage) or for very small operators.");
 
     // DistributedOperator + DefaultApproximationBuilder (distributed_operator/*.hpp)
     typedef PyDistributedOperator<T> Op;
