@@ -525,17 +525,19 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
 
     // recompression / openmp_recompression (hmatrix/hmatrix.hpp:96-99): SVD recompression on the device; the variant
     // taking a Python callable per low-rank matrix has no device counterpart and falls back to the built-in rule
-    auto recompress = [](H &s) {
+    auto recompress = [](H &s, double epsilon = -1.0) { // epsilon <= 0: the tolerance the H-matrix was built with
         int64_t n = 0;
-        check(htool_hmatrix_recompress(s.h, -1.0, &n));
+        check(htool_hmatrix_recompress(s.h, epsilon, &n));
         return n;
     };
     m.def("recompression", [recompress](H &s) { return recompress(s); });
+    m.def("recompression", [recompress](H &s, double epsilon) { return recompress(s, epsilon); }, "hmatrix"_a, "epsilon"_a); // extension: explicit tolerance
     m.def("recompression", [recompress](H &s, py::object) {
         python_log_sink(2, "recompression(hmatrix, fn): user-defined recompression callables are not supported on the HIP path; using the built-in SVD rule");
         return recompress(s);
     });
     m.def("openmp_recompression", [recompress](H &s) { return recompress(s); });
+    m.def("openmp_recompression", [recompress](H &s, double epsilon) { return recompress(s, epsilon); }, "hmatrix"_a, "epsilon"_a);
     m.def("openmp_recompression", [recompress](H &s, py::object) {
         python_log_sink(2, "openmp_recompression(hmatrix, fn): user-defined recompression callables are not supported on the HIP path; using the built-in SVD rule");
         return recompress(s);

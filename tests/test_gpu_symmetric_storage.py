@@ -211,6 +211,6 @@ def test_one_triangle_native_build_recompression(built, oracle, complex_):
     Htool.recompression(H, 1e-3)
     assert H.stats()["low_rank_elements"] < before
     e = np.linalg.norm(H * x - y_exact) / np.linalg.norm(y_exact)
-    assert 1e-8 < e < 5e-3
+    assert 3e-6 < e < 5e-3   # the explicit tolerance (1e-3) is honoured: coarser than the build's 1e-6
     H2 = copy.deepcopy(H)
     assert np.array_equal(H2 * x, H * x)
