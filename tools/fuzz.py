@@ -48,7 +48,9 @@ def main(budget, seed, only_case=None, with_oracle=False):
         arena = None if rng.rand() < 0.6 else int(10 ** rng.uniform(1.3, 2.7))
         recompress = rng.rand() < 0.3 and eps <= 1e-4
         shape = str(rng.choice(["ball", "cube", "sheet", "clustered"]))
-        label = dict(dim=dim, n=n, ns=ns, leaf=leaf, eta=eta, eps=float(f"{eps:.2e}"), kind=kind, sym=sym, uplo=uplo, one_tri=one_tri, children=children,
+        part = int(rng.choice([2, 3, 4, 8])) if (square and sym == "N" and rng.rand() < 0.35) else 1   # rows of one partition (a rank's share)
+        which = int(rng.randint(0, part))
+        label = dict(part=part, which=which, dim=dim, n=n, ns=ns, leaf=leaf, eta=eta, eps=float(f"{eps:.2e}"), kind=kind, sym=sym, uplo=uplo, one_tri=one_tri, children=children,
                      strategy=strategy, arena_mb=arena, recompress=bool(recompress), shape=shape, seed=seed, case=n_case)
 
         def cloud(m):
@@ -78,15 +80,27 @@ def main(budget, seed, only_case=None, with_oracle=False):
             cb = Htool.ClusterTreeBuilder()
             cb.set_maximal_leaf_size(leaf)
             cb.set_partitioning_strategy(getattr(Htool, strategy)())
-            ct = cb.create_cluster_tree(pt, children, size_of_partition=1)
+            ct = cb.create_cluster_tree(pt, children, size_of_partition=part)
             cs = ct if square else cb.create_cluster_tree(ps, children, size_of_partition=1)
             Builder = Htool.ComplexHMatrixTreeBuilder if cplx else Htool.HMatrixTreeBuilder
             Gen = Htool.ComplexNativeGenerator if cplx else Htool.NativeGenerator
             b = Builder(eps, eta, sym, uplo)
             b.set_symmetric_storage(one_tri)
             t0 = time.time()
-            H = b.build(Gen(kind, pt, ps, p0), ct, cs)
-            y = H * x
+            if part > 1:   # the per-rank operator of a row split: local rows in cluster order, x in user numbering
+                H = b.build(Gen(kind, pt, ps, p0), ct, cs, which)
+                sub = ct.get_cluster_on_partition(which)
+                perm = np.asarray(ct.get_permutation())
+                local_users = perm[sub.get_offset(): sub.get_offset() + sub.get_size()]
+                pick = rng.choice(len(local_users), min(len(local_users), 64), replace=False)
+                y_local = H * x
+                assert y_local.shape == (sub.get_size(),), y_local.shape
+                y = np.zeros(n, dtype=y_local.dtype)
+                y[local_users] = y_local
+                rows = local_users[pick]
+            else:
+                H = b.build(Gen(kind, pt, ps, p0), ct, cs)
+                y = H * x
             ye = exact_rows(kind, pt, ps, x, p0, rows)
             scale = np.linalg.norm(ye) + 1e-300
             err = np.linalg.norm(y[rows] - ye) / scale
@@ -94,15 +108,20 @@ def main(budget, seed, only_case=None, with_oracle=False):
             ok = np.all(np.isfinite(y)) and err < tol
             X = np.asfortranarray(np.stack([x, -x, 0.5 * x], axis=1))
             Y = H @ X
-            ok = ok and np.allclose(Y[:, 0], y, rtol=1e-11, atol=1e-13 * scale) and np.allclose(Y[:, 1], -y, rtol=1e-11, atol=1e-13 * scale)
+            y_ref = y if part == 1 else y[local_users]
+            ok = ok and np.allclose(Y[:, 0], y_ref, rtol=1e-11, atol=1e-13 * scale) and np.allclose(Y[:, 1], -y_ref, rtol=1e-11, atol=1e-13 * scale)
             if recompress:
                 H2 = copy.deepcopy(H)
                 Htool.recompression(H2, max(eps * 10, 1e-6))
                 y2 = H2 * x
+                if part > 1:
+                    full2 = np.zeros(n, dtype=y2.dtype)
+                    full2[local_users] = y2
+                    y2 = full2
                 err2 = np.linalg.norm(y2[rows] - ye) / scale
                 ok = ok and np.all(np.isfinite(y2)) and err2 < 20 * max(eps * 10, 1e-6) + tol
-                ok = ok and np.array_equal(H * x, y)  # the copy was recompressed, not the original
-            if with_oracle and square:  # the CPU restatement on the same input: is the error the algorithm's or the engine's?
+                ok = ok and np.array_equal(H * x, y_ref)  # the copy was recompressed, not the original
+            if with_oracle and square and part == 1:  # the CPU restatement on the same input: is the error the algorithm's or the engine's?
                 from oracle import oracle as O
                 oc = O.Cluster(pt, n_children=children, size_of_partition=1, max_leaf=leaf,
                                strategy={"PCARegular": 0, "PCAGeometric": 1, "BoundingBoxRegular": 2, "BoundingBoxGeometric": 3}[strategy])
