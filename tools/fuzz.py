@@ -69,6 +69,7 @@ def main(budget, seed, only_case=None, with_oracle=False):
             p0 = 0.1 if kind == "inv_delta" else (float(rng.uniform(1, 8)) if cplx else 0.0)
             x = rng.rand(ns) + (1j * rng.rand(ns) if cplx else 0)
             rows = rng.choice(n, min(n, 64), replace=False)
+            pick_rng = np.random.RandomState(rng.randint(0, 2 ** 31 - 1))   # (drawn here so that a replay consumes the same stream)
             if only_case is not None and n_case != only_case:
                 if n_case > only_case:
                     break
@@ -92,7 +93,7 @@ def main(budget, seed, only_case=None, with_oracle=False):
                 sub = ct.get_cluster_on_partition(which)
                 perm = np.asarray(ct.get_permutation())
                 local_users = perm[sub.get_offset(): sub.get_offset() + sub.get_size()]
-                pick = rng.choice(len(local_users), min(len(local_users), 64), replace=False)
+                pick = pick_rng.choice(len(local_users), min(len(local_users), 64), replace=False)
                 y_local = H * x
                 assert y_local.shape == (sub.get_size(),), y_local.shape
                 y = np.zeros(n, dtype=y_local.dtype)
