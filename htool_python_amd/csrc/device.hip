@@ -121,12 +121,21 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
         // use of the V panels, then the transposed dense results and the scatter to the caller's numbering
         if constexpr (NR == 1) {
             T *ycl = (T *)D->ycl;
+            auto launch_wide_sym = [&](const GTile *tiles, const int *cnt, T *dst) { // one launch per lane-packing class
+                const GTile *t = tiles;
+                const int cj = D->conj_transposed ? 1 : 0;
+                if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 1>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj);
+                t += cnt[0];
+                if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj);
+                t += cnt[1];
+                if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj);
+            };
             if (D->splitB > 1 && D->nB_split) { // small operator: column slices of the row tiles, summed in slice order
-                hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB_split), dim3(256), 0, st, D->tilesB_split, D->segs, (const T *)W, W, (T *)D->ypart, D->conj_transposed ? 1 : 0);
+                launch_wide_sym(D->tilesB_split, D->cntBs, (T *)D->ypart);
                 hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
                                    (const int *)nullptr, ycl, 0LL, 1);
             } else if (D->nB) {
-                hipLaunchKernelGGL((tile_gemv_wide_sym<Ops>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const T *)W, W, ycl, D->conj_transposed ? 1 : 0);
+                launch_wide_sym(D->tilesB_cluster, D->cntB, ycl);
             }
             if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, 1>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, 0LL);
             if (D->nAT) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, D->conj_transposed ? 1 : 0);
