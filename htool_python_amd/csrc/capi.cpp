@@ -1,6 +1,7 @@
 // capi.cpp -- extern "C" surface declared in include/htool_mi355x.h
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <sstream>
 #include <cmath>
@@ -165,13 +166,56 @@ void htool_build_params_default(htool_build_params *p) {
 }
 
 // ---- H-matrix ----------------------------------------------------------------------------------
+// leaves handed over by the caller instead of a generator (htool_hmatrix_build_from_leaves)
+struct LeafPreset {
+    int is_complex;
+    int64_t n_leaves;
+    const int *leaves5;
+    const int64_t *offsets2;
+    const void *data;
+    int64_t n_elements;
+};
+
+static void fill_from_preset(HMatrix &H, const LeafPreset &ps) {
+    const ClusterTree &T = *H.tc, &S = *H.sc;
+    auto index_nodes = [](const ClusterTree &C) {
+        std::map<std::pair<int, int>, int> m; // (offset, size) -> node; the first (shallowest) node of a range wins
+        for (int id = 0; id < C.node_count(); id++) m.emplace(std::make_pair(C.offset[id], C.size[id]), id);
+        return m;
+    };
+    const auto tn = index_nodes(T), sn = (&T == &S) ? tn : index_nodes(S);
+    H.blocks.clear();
+    H.blocks.reserve((size_t)ps.n_leaves);
+    for (int64_t i = 0; i < ps.n_leaves; i++) {
+        const int *l = ps.leaves5 + 5 * i;
+        auto it = tn.find(std::make_pair(l[0], l[1]));
+        auto is = sn.find(std::make_pair(l[2], l[3]));
+        HM_CHECK(it != tn.end() && is != sn.end(), strprintf("leaf %lld (%d,%d,%d,%d) does not match a pair of cluster nodes", (long long)i, l[0], l[1], l[2], l[3]));
+        HM_CHECK(l[0] >= H.row_off && l[0] + l[1] <= H.row_off + H.row_size && l[2] >= H.col_off && l[2] + l[3] <= H.col_off + H.col_size, "leaf outside the operator");
+        BlockRec b;
+        b.t_node = it->second; b.s_node = is->second;
+        b.t_off = l[0]; b.m = l[1]; b.s_off = l[2]; b.n = l[3];
+        b.rank = l[4]; b.cap = std::max(l[4], 0); b.batch = -1;
+        b.tmp_u = ps.offsets2[2 * i]; b.tmp_v = ps.offsets2[2 * i + 1];
+        b.ucol = b.vcol = 0; b.tpos = 0; b.v_obase = 0; b.v_ostride = 0; b.status = 0;
+        const int64_t lu = (int64_t)(b.rank >= 0 ? b.rank : b.n) * b.m, lv = b.rank > 0 ? (int64_t)b.rank * b.n : 0;
+        HM_CHECK(b.rank >= -1 && b.rank <= std::min(b.m, b.n), "leaf with an impossible rank");
+        HM_CHECK(b.tmp_u >= 0 && b.tmp_u + lu <= ps.n_elements && (lv == 0 || (b.tmp_v >= 0 && b.tmp_v + lv <= ps.n_elements)), "leaf data outside the buffer");
+        if (H.one_triangle) {
+            const bool lower = H.params.uplo == 'L';
+            HM_CHECK(lower ? b.s_off < b.t_off + b.m : b.t_off < b.s_off + b.n, "one-triangle storage: a leaf lies in the triangle that is not stored");
+        }
+        H.blocks.push_back(b);
+    }
+}
+
 static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
-                                    const htool_build_params *params, int target_partition, int source_partition = -1) {
-    HM_CHECK(g && target_root && source_root && params, "htool_hmatrix_build: null argument");
+                                    const htool_build_params *params, int target_partition, int source_partition = -1, const LeafPreset *preset = nullptr) {
+    HM_CHECK((g || preset) && target_root && source_root && params, "htool_hmatrix_build: null argument");
     ClusterTree *T = CH(target_root)->tree, *S = CH(source_root)->tree;
     HM_CHECK(params->symmetry == 'N' || params->symmetry == 'S' || params->symmetry == 'H', "symmetry must be 'N', 'S' or 'H'");
     HM_CHECK(params->uplo == 'N' || params->uplo == 'L' || params->uplo == 'U', "UPLO must be 'N', 'L' or 'U'");
-    if (g->g.native) {
+    if (g && g->g.native) {
         HM_CHECK(g->g.n_target == T->n_points && g->g.n_source == S->n_points, "native generator: point counts do not match the clusters");
         HM_CHECK(g->g.dim == T->dim && g->g.dim == S->dim, "native generator: dimension does not match the clusters");
     }
@@ -180,7 +224,7 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     HMatrix &H = h->H;
     H.tc = T;
     H.sc = S;
-    H.is_complex = g->g.is_complex;
+    H.is_complex = preset ? preset->is_complex != 0 : g->g.is_complex;
     H.params.epsilon = params->epsilon;
     H.params.eta = params->eta;
     H.params.symmetry = params->symmetry;
@@ -219,7 +263,10 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     h->tch = T->handle(H.t_root);
     h->sch = S->handle(H.s_root);
     double t0 = wall_seconds();
-    if (g->g.native) {
+    if (preset) {
+        fill_from_preset(H, *preset);
+        device_build_from_host(H, preset->data, preset->n_elements);
+    } else if (g->g.native) {
         device_build_native(H, g->g);
     } else if (H.is_complex) {
         std::vector<cplx> arena;
@@ -249,6 +296,16 @@ int htool_hmatrix_build_local(const htool_generator *g, const htool_cluster *tar
     *out = h;
     API_END
 }
+int htool_hmatrix_build_from_leaves(const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
+                                    int is_complex, int target_partition_number, int64_t n_leaves, const int *leaves5,
+                                    const int64_t *offsets2, const void *data, int64_t n_elements, htool_hmatrix **out) {
+    API_BEGIN
+    HM_CHECK(n_leaves >= 0 && (n_leaves == 0 || (leaves5 && offsets2)) && (n_elements == 0 || data), "htool_hmatrix_build_from_leaves: null argument");
+    LeafPreset ps{is_complex, n_leaves, leaves5, offsets2, data, n_elements};
+    *out = build_hmatrix(nullptr, target_root, source_root, params, target_partition_number, -1, &ps);
+    API_END
+}
+int htool_hmatrix_is_one_triangle(const htool_hmatrix *h) { return h->H.one_triangle ? 1 : 0; }
 void htool_hmatrix_destroy(htool_hmatrix *h) { delete h; }
 int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     API_BEGIN

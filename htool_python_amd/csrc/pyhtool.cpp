@@ -508,6 +508,7 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 d["sum_rank"] = st[4]; d["hbm_bytes"] = st[5]; d["build_seconds"] = st[6] * 1e-6; d["max_rank"] = st[7];
                 return d;
             })
+        .def("is_one_triangle", [](const H &s) { return htool_hmatrix_is_one_triangle(s.h) != 0; })
         .def("set_phase_timing", [](const H &s, bool on) { check(htool_hmatrix_set_phase_timing(s.h, on ? 1 : 0)); }, "on"_a = true)
         .def("last_product_us", [](const H &s) { return htool_hmatrix_last_product_us(s.h); })
         .def("phase_times_us", [](const H &s) {
@@ -522,6 +523,25 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 check(htool_hmatrix_matmat_device(s.h, (const void *)x_dev, ldx, (void *)y_dev, ldy, mu, numbering, (void *)stream));
             }, "x_ptr"_a, "ldx"_a, "y_ptr"_a, "ldy"_a, "mu"_a, "numbering"_a = 0, "stream"_a = 0)
         .def_property_readonly("_handle", [](const H &s) { return (std::uintptr_t)s.h; });
+
+    // checkpoint / resume: rebuild an H-matrix from leaves and panels saved by htool_python_amd/io.py
+    m.def(("_" + std::string(std::is_same<T, double>::value ? "" : "complex_") + "hmatrix_from_leaves").c_str(),
+          [](const PyCluster &target, const PyCluster &source, double epsilon, double eta, char symmetry, char UPLO, bool one_triangle, int target_partition_number,
+             py::array_t<int, py::array::c_style | py::array::forcecast> leaves, py::array_t<int64_t, py::array::c_style | py::array::forcecast> offsets,
+             py::array_t<T, py::array::c_style | py::array::forcecast> data) {
+              if (leaves.ndim() != 2 || leaves.shape(1) != 5 || offsets.ndim() != 2 || offsets.shape(1) != 2 || offsets.shape(0) != leaves.shape(0) || data.ndim() != 1)
+                  throw std::runtime_error("hmatrix_from_leaves: leaves must be (n, 5), offsets (n, 2), data one-dimensional");
+              htool_build_params p;
+              htool_build_params_default(&p);
+              p.epsilon = epsilon; p.eta = eta; p.symmetry = symmetry; p.uplo = UPLO; p.store_one_triangle = one_triangle ? 1 : 0;
+              H out;
+              out.target = target;
+              out.source = source;
+              check(htool_hmatrix_build_from_leaves(target.owner->root, source.owner->root, &p, std::is_same<T, double>::value ? 0 : 1, target_partition_number,
+                                                    (int64_t)leaves.shape(0), leaves.data(), offsets.data(), data.data(), (int64_t)data.size(), &out.h));
+              return out;
+          }, "target_cluster"_a, "source_cluster"_a, "epsilon"_a, "eta"_a, "symmetry"_a, "UPLO"_a, "one_triangle"_a, "target_partition_number"_a, "leaves"_a,
+          "offsets"_a, "data"_a);
 
     // recompression / openmp_recompression (hmatrix/hmatrix.hpp:96-99): SVD recompression on the device; the variant
     // taking a Python callable per low-rank matrix has no device counterpart and falls back to the built-in rule

@@ -197,6 +197,17 @@ int htool_hmatrix_leaf_panels(const htool_hmatrix *h, int64_t leaf, void *A, voi
 int htool_hmatrix_leaf_panels_bulk(const htool_hmatrix *h, int64_t n, const int64_t *leaf_ids, int64_t *offsets2, void *out,
                                    int64_t *n_elements);
 
+/* Rebuild an H-matrix from its leaves (checkpoint / resume): leaves5 = n_leaves x (t_off, m, s_off, n,
+ * rank) as returned by htool_hmatrix_leaves, offsets2 / data as returned by htool_hmatrix_leaf_panels_bulk for ALL
+ * leaves (dense block or U at offsets2[2i], V at offsets2[2i+1], elements of the coefficient type).  The clusters must
+ * be the trees the leaves were computed on (same offsets and sizes); params carries epsilon / eta / symmetry / UPLO for
+ * the information entries and store_one_triangle = 1 when the leaves hold one triangle of a symmetric operator. */
+int htool_hmatrix_build_from_leaves(const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
+                                    int is_complex, int target_partition_number, int64_t n_leaves, const int *leaves5,
+                                    const int64_t *offsets2, const void *data, int64_t n_elements, htool_hmatrix **out);
+/* 1 when the handle stores one triangle of a symmetric / Hermitian operator */
+int htool_hmatrix_is_one_triangle(const htool_hmatrix *h);
+
 /* get_tree_parameters / get_local_information (hmatrix.hpp:50-52): "key=value\n" lines copied
  * into buf (truncated to cap); returns needed size. which: 0 tree parameters, 1 local information */
 int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap);

@@ -397,3 +397,51 @@ def test_block_jacobi_preconditioned_gmres(built, oracle, symmetry, uplo):
     info = solver.get_information()
     assert "block-jacobi" in info["Preconditioner"] and int(info["Nb_it"]) == prec["iterations"]
     assert np.linalg.norm(A @ xs - b) / np.linalg.norm(b) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["native_sym", "callback_complex", "partition", "recompressed"])
+def test_save_and_load_hmatrix(built, oracle, tmp_path, case):
+    """Checkpoint / resume: save leaves + panels to .npz, rebuild on the same cluster trees without any
+    generator call; same leaf table, same product to rounding, wrong trees are refused."""
+    import Htool
+    from tests.helpers import ComplexNumpyGenerator, cluster_of
+
+    O = oracle
+    n = 3000
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    part = -1
+    if case == "native_sym":
+        cl = cluster_of(pts, 25, size_of_partition=1)
+        H = Htool.HMatrixTreeBuilder(1e-5, 10.0, "S", "L").build(Htool.NativeGenerator("inv_delta", pts, pts, 0.1), cl, cl)
+        assert H.is_one_triangle()
+    elif case == "callback_complex":
+        cl = cluster_of(pts[:, :1200], 20, size_of_partition=1)
+        gen = ComplexNumpyGenerator(pts[:, :1200], pts[:, :1200], 4.0)
+        H = Htool.ComplexHMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(gen, cl, cl)
+    elif case == "partition":
+        cl = cluster_of(pts, 30, size_of_partition=3)
+        part = 1
+        H = Htool.HMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts, 0.0), cl, cl, part)
+    else:
+        cl = cluster_of(pts, 16, size_of_partition=1)
+        H = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts, 0.0), cl, cl)
+        Htool.recompression(H, 1e-3)
+    path = str(tmp_path / "operator.npz")
+    Htool.save_hmatrix(path, H)
+    H2 = Htool.load_hmatrix(path, cl, target_partition_number=part)
+    assert type(H2) is type(H) and H2.shape == H.shape and H2.is_one_triangle() == H.is_one_triangle()
+    L1 = {tuple(l) for l in np.asarray(H.leaves()).tolist()}
+    L2 = {tuple(l) for l in np.asarray(H2.leaves()).tolist()}
+    assert L1 == L2
+    ncol = H.shape[1]
+    x = np.random.rand(ncol) + (1j * np.random.rand(ncol) if case == "callback_complex" else 0)
+    y1, y2 = H * x, H2 * x
+    assert np.linalg.norm(y1 - y2) / np.linalg.norm(y1) < 1e-13
+    assert H2.get_tree_parameters()["Epsilon"] == H.get_tree_parameters()["Epsilon"]
+    X = np.asfortranarray(np.stack([x, 2 * x], axis=1))
+    assert np.linalg.norm(H2 @ X - H @ X) / np.linalg.norm(H @ X) < 1e-13
+    # a different tree is refused
+    other = cluster_of(pts[:, ::-1].copy() if case != "callback_complex" else pts[:, 1200:2400], 25, size_of_partition=3 if case == "partition" else 1)
+    with pytest.raises(RuntimeError):
+        Htool.load_hmatrix(path, other, target_partition_number=part)
