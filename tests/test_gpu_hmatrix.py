@@ -445,3 +445,19 @@ def test_save_and_load_hmatrix(built, oracle, tmp_path, case):
     other = cluster_of(pts[:, ::-1].copy() if case != "callback_complex" else pts[:, 1200:2400], 25, size_of_partition=3 if case == "partition" else 1)
     with pytest.raises(RuntimeError):
         Htool.load_hmatrix(path, other, target_partition_number=part)
+
+
+def test_randomised_stress_short(built):
+    """25 s of tools/fuzz.py with a fixed seed: random geometry / leaf size / eta / eps / kernel / storage / partition /
+    arena size / recompression cases against sampled exact rows (longer runs: `python tools/fuzz.py 600 <seed>`)."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz.py")
+    spec = importlib.util.spec_from_file_location("fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        assert mod.main(25.0, 3) == 0
+    finally:
+        os.environ.pop("HTOOL_BUILD_ARENA_MB", None)
