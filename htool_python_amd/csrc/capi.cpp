@@ -166,6 +166,14 @@ void htool_build_params_default(htool_build_params *p) {
 }
 
 // ---- H-matrix ----------------------------------------------------------------------------------
+// the same cluster tree, or two trees built alike on the same points (the reference's example builds the target and the
+// source cluster separately, example/use_hmatrix.py:27-28): same permutation and same node table
+static bool same_tree(const ClusterTree *T, const ClusterTree *S) {
+    if (T == S) return true;
+    return T->n_points == S->n_points && T->perm == S->perm && T->offset == S->offset && T->size == S->size && T->first_child == S->first_child &&
+           T->n_child == S->n_child && T->cx == S->cx && T->cy == S->cy && T->cz == S->cz && T->radius == S->radius;
+}
+
 // leaves handed over by the caller instead of a generator (htool_hmatrix_build_from_leaves)
 struct LeafPreset {
     int is_complex;
@@ -238,7 +246,7 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     H.params.dense_blocks = params->dense_blocks;
     H.params.dense_blocks_ctx = params->dense_blocks_ctx;
     if (params->store_one_triangle) {
-        const bool eligible = (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition < 0 && source_partition < 0;
+        const bool eligible = (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && same_tree(T, S) && target_partition < 0 && source_partition < 0;
         if (eligible) { H.params.store_one_triangle = 1; H.one_triangle = true; }
         else if (params->symmetry != 'N') log_message(LOG_DEBUG, "symmetric build restricted to a partition or on two cluster trees: both triangles of the requested rows are stored");
     }
@@ -565,7 +573,7 @@ int htool_block_tree_queues(const htool_cluster *target_root, const htool_cluste
     P.uplo = params->uplo;
     P.min_target_depth = params->minimal_target_depth;
     P.min_source_depth = params->minimal_source_depth;
-    if (params->store_one_triangle && (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && T == S && target_partition_number < 0)
+    if (params->store_one_triangle && (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && same_tree(T, S) && target_partition_number < 0)
         P.store_one_triangle = 1;
     int t_root = 0;
     if (target_partition_number >= 0) {

@@ -214,3 +214,25 @@ def test_one_triangle_native_build_recompression(built, oracle, complex_):
     assert 3e-6 < e < 5e-3   # the explicit tolerance (1e-3) is honoured: coarser than the build's 1e-6
     H2 = copy.deepcopy(H)
     assert np.array_equal(H2 * x, H * x)
+
+
+def test_one_triangle_with_separately_built_identical_trees(built, oracle):
+    """The reference's example builds the target and the source cluster separately from the same points
+    (example/use_hmatrix.py:27-28) and asks for 'S','L': two structurally identical trees count as one."""
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    n = 2500
+    np.random.seed(0)
+    pts = O.points_in_sphere(n)
+    tcl, scl = cluster_of(pts, 50), cluster_of(pts, 50)
+    H = Htool.HMatrixTreeBuilder(1e-4, 10.0, "S", "L").build(Htool.NativeGenerator("inv_delta", pts, pts, 0.1), tcl, scl)
+    assert H.is_one_triangle()
+    x = np.random.rand(n)
+    y_exact = O.dense_matvec(0, pts, pts, x, 0.1)
+    assert np.linalg.norm(H * x - y_exact) / np.linalg.norm(y_exact) < 1e-4
+    other = cluster_of(pts, 30)   # a different tree on the same points (one more level): not symmetric storage
+    H2 = Htool.HMatrixTreeBuilder(1e-4, 10.0, "S", "L").build(Htool.NativeGenerator("inv_delta", pts, pts, 0.1), tcl, other)
+    assert not H2.is_one_triangle()
+    assert np.linalg.norm(H2 * x - y_exact) / np.linalg.norm(y_exact) < 1e-4
