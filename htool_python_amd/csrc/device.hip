@@ -119,30 +119,34 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     if (D->one_triangle) {
         // fused sweep: y (cluster numbering) and the transposed dot products of every column, then the transposed
         // use of the V panels, then the transposed dense results and the scatter to the caller's numbering
-        if constexpr (NR == 1) {
+        if constexpr (NR <= 4) {
             T *ycl = (T *)D->ycl;
-            auto launch_wide_sym = [&](const GTile *tiles, const int *cnt, T *dst) { // one launch per lane-packing class
+            const long long ys = D->ycl_stride;
+            const int cj = D->conj_transposed ? 1 : 0;
+            auto launch_wide_sym = [&](const GTile *tiles, const int *cnt, T *dst, long long dst_stride) { // one launch per lane-packing class
                 const GTile *t = tiles;
-                const int cj = D->conj_transposed ? 1 : 0;
-                if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 1>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj);
+                if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 1, NR>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
                 t += cnt[0];
-                if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj);
+                if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2, NR>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
                 t += cnt[1];
-                if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj);
+                if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4, NR>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
             };
             if (D->splitB > 1 && D->nB_split) { // small operator: column slices of the row tiles, summed in slice order
-                launch_wide_sym(D->tilesB_split, D->cntBs, (T *)D->ypart);
+                launch_wide_sym(D->tilesB_split, D->cntBs, (T *)D->ypart, (long long)D->splitB * D->ypart_stride);
                 hipLaunchKernelGGL(reduce_y_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)D->ypart, D->ypart_stride, D->splitB, D->row_size,
-                                   (const int *)nullptr, ycl, 0LL, 1);
+                                   (const int *)nullptr, ycl, ys, NR);
             } else if (D->nB) {
-                launch_wide_sym(D->tilesB_cluster, D->cntB, ycl);
+                launch_wide_sym(D->tilesB_cluster, D->cntB, ycl, ys);
             }
-            if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, 1>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, 0LL);
-            if (D->nAT) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, D->conj_transposed ? 1 : 0);
+            if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, ws);
+            if (D->nAT) {
+                if constexpr (NR == 1) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, cj);
+                else hipLaunchKernelGGL((tile_gemv_tall_transposed_multi<Ops, NR>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, cj, ws, ys);
+            }
             if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym_kernel<T>, dim3(D->n_zd_tiles), dim3(128), 0, st, (const T *)ycl, (const T *)W, D->zd_ptr, D->zd_woff, D->zd_rows,
-                                                  out_user ? D->perm_t : (const int *)nullptr, (T *)y_dev);
+                                                  out_user ? D->perm_t : (const int *)nullptr, (T *)y_dev, NR, ys, ws, y_stride);
         } else {
-            throw Error("one-triangle storage: products are swept one right-hand side at a time");
+            throw Error("one-triangle storage: at most four right-hand sides per fused sweep");
         }
     } else if (D->splitB > 1 && D->nB_split) {
         const long long ps = (long long)D->splitB * D->ypart_stride;
@@ -179,8 +183,22 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
             HIP_OK(hipMemcpy(D->segs + x.seg_begin, &sg, sizeof(GSeg), hipMemcpyHostToDevice));
         }
     }
+    if (D->W && D->nZ) { // so do the panels of the transposed partial sums (one-triangle storage)
+        std::vector<GTile> t((size_t)D->nZ);
+        HIP_OK(hipMemcpy(t.data(), D->tilesZ, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
+        for (auto &x : t) {
+            GSeg sg;
+            HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
+            sg.panel = (const char *)nW + ((const char *)sg.panel - (const char *)D->W);
+            HIP_OK(hipMemcpy(D->segs + x.seg_begin, &sg, sizeof(GSeg), hipMemcpyHostToDevice));
+        }
+    }
     if (D->W) (void)hipFree(D->W);
     D->W = nW;
+    if (D->one_triangle) {
+        if (D->ycl) (void)hipFree(D->ycl);
+        HIP_OK(dev_malloc(&D->ycl, (size_t)nr * std::max<long long>(D->ycl_stride, 1) * sizeof(T)));
+    }
     if (D->splitB > 1) {
         if (D->ypart) (void)hipFree(D->ypart);
         HIP_OK(dev_malloc(&D->ypart, (size_t)nr * D->splitB * D->ypart_stride * sizeof(T)));
@@ -196,7 +214,12 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
         const int left = mu - done;
         const T *x = (const T *)X + (long long)done * x_stride;
         T *y = (T *)Y + (long long)done * y_stride;
-        if (D->one_triangle) { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; continue; }
+        if (D->one_triangle) { // fused sweeps take up to four right-hand sides
+            if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
+            else if (left >= 2) { launch_sweep<Ops, 2>(D, x, x_stride, y, y_stride, numbering, st); done += 2; }
+            else { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; }
+            continue;
+        }
         if (left >= 8) { launch_sweep<Ops, 8>(D, x, x_stride, y, y_stride, numbering, st); done += 8; }
         else if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
         else if (left >= 2) { launch_sweep<Ops, 2>(D, x, x_stride, y, y_stride, numbering, st); done += 2; }
@@ -210,7 +233,7 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
-    const int need = D->one_triangle ? 1 : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
+    const int need = D->one_triangle ? (mu >= 4 ? 4 : mu >= 2 ? 2 : 1) : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
     if (need > D->rhs_cap) {
         HIP_OK(hipStreamSynchronize(st));
         if (D->is_complex) ensure_rhs_capacity<double2>(D, need);

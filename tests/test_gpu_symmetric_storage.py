@@ -59,11 +59,13 @@ def test_one_triangle_matches_cpu_storage_and_product(built, oracle, n, leaf, et
     assert np.linalg.norm(y - y_cpu) / np.linalg.norm(y_cpu) < 2 * eps
     # bitwise reproducible (fixed summation order, no atomics)
     assert np.array_equal(H * x, y)
-    # several right-hand sides go through the same sweep one at a time
-    X = np.asfortranarray(np.random.rand(n, 3))
+    # several right-hand sides: fused sweeps of 4, 2 and 1 columns (other reduction order than the single-column kernel)
+    X = np.asfortranarray(np.random.rand(n, 7))
     Y = H @ X
-    for j in range(3):
-        assert np.array_equal(Y[:, j], H * np.ascontiguousarray(X[:, j]))
+    for j in range(7):
+        yj = H * np.ascontiguousarray(X[:, j])
+        assert np.linalg.norm(Y[:, j] - yj) / np.linalg.norm(yj) < 1e-13
+    assert np.array_equal(H @ X, Y)
 
 
 def test_one_triangle_equals_two_triangle_operator(built, oracle):
@@ -114,6 +116,11 @@ def test_one_triangle_complex_symmetric(built, oracle):
     OH = O.HMatrix(oc, oc, 2, kappa, is_complex=True, eps=eps, eta=eta, symmetry="S", uplo="L")
     assert {tuple(l[:4]) for l in np.asarray(H.leaves())} == {tuple(l[:4]) for l in OH.leaves}
     assert np.linalg.norm(y - OH.matvec(x)) / np.linalg.norm(y) < 2 * eps
+    X = np.asfortranarray(np.random.rand(n, 6) + 1j * np.random.rand(n, 6))
+    Y = H @ X
+    for j in range(6):
+        yj = H * np.ascontiguousarray(X[:, j])
+        assert np.linalg.norm(Y[:, j] - yj) / np.linalg.norm(yj) < 1e-13
 
 
 def test_one_triangle_callback_generator_copy_and_recompression(built, oracle):
@@ -185,6 +192,8 @@ def test_one_triangle_hermitian(built, oracle):
         assert all((l[2] < l[0] + l[1]) if uplo == "L" else (l[0] < l[2] + l[3]) for l in L)
         y = H * x
         assert np.linalg.norm(y - A @ x) / np.linalg.norm(A @ x) < eps
+        X = np.asfortranarray(np.random.rand(n, 5) + 1j * np.random.rand(n, 5))
+        assert np.linalg.norm(H @ X - A @ X) / np.linalg.norm(A @ X) < eps
         D = H.to_dense_in_user_numbering()
         assert np.linalg.norm(D - A) / np.linalg.norm(A) < eps
         assert np.abs(D - D.conj().T).max() < 1e-12 * np.abs(D).max()
