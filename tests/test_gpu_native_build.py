@@ -492,3 +492,34 @@ def test_no_device_memory_leak(built, oracle):
         Htool.release_workspace()
         marks.append(free_bytes())
     assert abs(marks[-1] - marks[0]) < 32 << 20, marks
+
+
+def test_more_work_items_than_one_launch_can_hold(built, oracle):
+    """Millions of tiny leaves: the pack kernels have one workgroup per (leaf, tile) pair, and 26 million of them exceed
+    the 2^32 work-items a single launch can address (the excess was silently dropped before the launches were sliced).
+    Found by tools/fuzz.py (seed 44, case 538)."""
+    import Htool
+    from tools.fuzz import exact_rows
+
+    rng = np.random.RandomState(5)
+
+    def ball(m):
+        p = rng.randn(3, m)
+        p /= np.linalg.norm(p, axis=0)
+        return np.asfortranarray(p * rng.rand(m) ** (1.0 / 3))
+
+    n, ns, eps = 91668, 112393, 1.55e-3
+    pt, ps = ball(n), np.asfortranarray(ball(ns) + 0.3)
+    cb = Htool.ClusterTreeBuilder()
+    cb.set_maximal_leaf_size(5)
+    cb.set_partitioning_strategy(Htool.BoundingBoxRegular())
+    ct, cs = cb.create_cluster_tree(pt, 4, size_of_partition=1), cb.create_cluster_tree(ps, 4, size_of_partition=1)
+    H = Htool.HMatrixTreeBuilder(eps, 0.7, "N", "N").build(Htool.NativeGenerator("laplace", pt, ps, 0.0), ct, cs)
+    st = H.stats()
+    assert st["n_dense"] + st["n_low_rank"] > 8_000_000
+    x = rng.rand(ns)
+    y = H * x
+    rows = rng.choice(n, 500, replace=False)
+    ye = exact_rows("laplace", pt, ps, x, 0.0, rows)
+    assert np.linalg.norm(y[rows] - ye) / np.linalg.norm(ye) < eps
+    Htool.release_workspace()

@@ -69,7 +69,8 @@ def main(budget, seed, only_case=None, with_oracle=False):
             p0 = 0.1 if kind == "inv_delta" else (float(rng.uniform(1, 8)) if cplx else 0.0)
             x = rng.rand(ns) + (1j * rng.rand(ns) if cplx else 0)
             rows = rng.choice(n, min(n, 64), replace=False)
-            pick_rng = np.random.RandomState(rng.randint(0, 2 ** 31 - 1))   # (drawn here so that a replay consumes the same stream)
+            pick_rng = np.random.RandomState(rng.randint(0, 2 ** 31 - 1))
+            case_cols = pick_rng.randint(0, 5)   # 3 .. 7 right-hand sides: sweeps of 8 / 4 / 2 / 1 columns   # (drawn here so that a replay consumes the same stream)
             if only_case is not None and n_case != only_case:
                 if n_case > only_case:
                     break
@@ -107,7 +108,7 @@ def main(budget, seed, only_case=None, with_oracle=False):
             err = np.linalg.norm(y[rows] - ye) / scale
             tol = 20 * eps   # sampled rows: the Frobenius-type bound of the operator is looser row by row
             ok = np.all(np.isfinite(y)) and err < tol
-            X = np.asfortranarray(np.stack([x, -x, 0.5 * x], axis=1))
+            X = np.asfortranarray(np.stack([x, -x, 0.5 * x, x, 2 * x, x, -x][: int(3 + case_cols)], axis=1))
             Y = H @ X
             y_ref = y if part == 1 else y[local_users]
             ok = ok and np.allclose(Y[:, 0], y_ref, rtol=1e-11, atol=1e-13 * scale) and np.allclose(Y[:, 1], -y_ref, rtol=1e-11, atol=1e-13 * scale)
@@ -122,11 +123,12 @@ def main(budget, seed, only_case=None, with_oracle=False):
                 err2 = np.linalg.norm(y2[rows] - ye) / scale
                 ok = ok and np.all(np.isfinite(y2)) and err2 < 20 * max(eps * 10, 1e-6) + tol
                 ok = ok and np.array_equal(H * x, y_ref)  # the copy was recompressed, not the original
-            if with_oracle and square and part == 1:  # the CPU restatement on the same input: is the error the algorithm's or the engine's?
+            if with_oracle and part == 1:  # the CPU restatement on the same input: is the error the algorithm's or the engine's?
                 from oracle import oracle as O
-                oc = O.Cluster(pt, n_children=children, size_of_partition=1, max_leaf=leaf,
-                               strategy={"PCARegular": 0, "PCAGeometric": 1, "BoundingBoxRegular": 2, "BoundingBoxGeometric": 3}[strategy])
-                OH = O.HMatrix(oc, oc, {"inv_delta": 0, "laplace": 1, "helmholtz": 2}[kind], p0, is_complex=cplx, eps=eps, eta=eta, symmetry=sym, uplo=uplo)
+                sid = {"PCARegular": 0, "PCAGeometric": 1, "BoundingBoxRegular": 2, "BoundingBoxGeometric": 3}[strategy]
+                oc = O.Cluster(pt, n_children=children, size_of_partition=1, max_leaf=leaf, strategy=sid)
+                ocs = oc if square else O.Cluster(ps, n_children=children, size_of_partition=1, max_leaf=leaf, strategy=sid)
+                OH = O.HMatrix(oc, ocs, {"inv_delta": 0, "laplace": 1, "helmholtz": 2}[kind], p0, is_complex=cplx, eps=eps, eta=eta, symmetry=sym, uplo=uplo)
                 yo = OH.matvec(x)
                 print(f"   oracle: err {np.linalg.norm(yo[rows] - ye) / scale:.2e}, |y - y_oracle|/|y| {np.linalg.norm(y - yo) / np.linalg.norm(yo):.2e}", flush=True)
             print(("ok  " if ok else "FAIL"), f"{time.time() - t0:6.2f}s err {err:.2e}", label, flush=True)
