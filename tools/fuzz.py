@@ -32,7 +32,7 @@ def main(budget, seed, only_case=None, with_oracle=False):
     while time.time() < t_end:
         n_case += 1
         dim = int(rng.choice([2, 3]))
-        n = int(10 ** rng.uniform(2.5, 5.2))
+        n = int(10 ** rng.uniform(2.5, float(os.environ.get("FUZZ_MAX_LOG10_N", "5.2"))))
         square = rng.rand() < 0.75
         ns = n if square else int(n * rng.uniform(0.3, 1.5))
         leaf = int(rng.choice([3, 5, 10, 16, 33, 50, 64, 100, 130, 257, 600]))
