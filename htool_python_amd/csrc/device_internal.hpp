@@ -9,10 +9,16 @@
 
 namespace hm {
 
+// A failing HIP call also leaves its code behind as the runtime's sticky "last error": it is cleared here, otherwise the
+// next HIP_OK(hipGetLastError()) after an unrelated kernel launch would report it again (cascading failures after one
+// out-of-memory condition).
 #define HIP_OK(call)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
-        if (e_ != hipSuccess) throw hm::Error(hm::strprintf("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call)); \
+        if (e_ != hipSuccess) {                                                                              \
+            (void)hipGetLastError();                                                                         \
+            throw hm::Error(hm::strprintf("HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #call)); \
+        }                                                                                                    \
     } while (0)
 
 // one column segment of a tile panel (device view); T elements are double (real) or double2 (complex)
