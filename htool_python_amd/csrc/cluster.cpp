@@ -10,6 +10,8 @@
 #include "cluster.hpp"
 
 #include <algorithm>
+#include <parallel/algorithm>
+#include <omp.h>
 #include <cmath>
 #include <numeric>
 
@@ -97,7 +99,9 @@ void dominant_axis(double a[3][3], int d, double dir[3]) {
 }
 
 // sorts perm[off, off+sz) along the split direction, returns the piece sizes
-std::vector<int> split_range(ClusterTree &T, const double *weights, int off, int sz, const double centre[3], int pieces, int strategy) {
+// parallel_sort: the caller is not inside a parallel region (top levels of the tree: few, large nodes) -- the sort then
+// uses all threads; a stable sort has a unique result, so the permutation does not depend on the thread count
+std::vector<int> split_range(ClusterTree &T, const double *weights, int off, int sz, const double centre[3], int pieces, int strategy, bool parallel_sort = false) {
     const int d = T.dim;
     double dir[3] = {1, 0, 0};
     const bool pca = strategy == 0 || strategy == 1, regular = strategy == 0 || strategy == 2;
@@ -128,13 +132,18 @@ std::vector<int> split_range(ClusterTree &T, const double *weights, int off, int
         for (int k = 0; k < 3; k++) dir[k] = k == best;
     }
     std::vector<std::pair<double, int>> key(sz);
+    const bool par = parallel_sort && sz >= 65536;
+#pragma omp parallel for schedule(static) if (par)
     for (int i = 0; i < sz; i++) {
         int u = T.perm[off + i];
         double s = 0;
         for (int k = 0; k < d; k++) s += (T.coords[(size_t)u * d + k] - centre[k]) * dir[k];
         key[i] = std::make_pair(s, u);
     }
-    std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; });
+    auto by_projection = [](const std::pair<double, int> &a, const std::pair<double, int> &b) { return a.first < b.first; };
+    if (par) __gnu_parallel::stable_sort(key.begin(), key.end(), by_projection);
+    else std::stable_sort(key.begin(), key.end(), by_projection);
+#pragma omp parallel for schedule(static) if (par)
     for (int i = 0; i < sz; i++) T.perm[off + i] = key[i].second;
     std::vector<int> sizes(pieces, 0);
     if (regular) {
@@ -218,7 +227,7 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
             for (int i = 0; i < a.n_points; i++) np[start[a.partition[i]]++] = i;
             T.perm.swap(np);
         } else {
-            sizes = split_range(T, a.weights, 0, a.n_points, g0.c, P, a.strategy);
+            sizes = split_range(T, a.weights, 0, a.n_points, g0.c, P, a.strategy, true);
         }
         T.first_child[0] = 1;
         T.n_child[0] = P;
@@ -240,21 +249,23 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
     const int nc = a.n_children;
     while (!level.empty()) {
         std::vector<Split> res(level.size());
-#pragma omp parallel for schedule(dynamic, 1)
-        for (long q = 0; q < (long)level.size(); q++) {
+        // few, large nodes (top of the tree): one node after the other, each sorted by all threads; later levels: the
+        // nodes in parallel, each sorted by one thread
+        const bool wide_level = (int)level.size() >= 2 * omp_get_max_threads();
+        auto split_node = [&](long q) {
             int id = level[q], off = T.offset[id], sz = T.size[id];
             Split &s = res[q];
             s.ok = false;
-            if (sz / nc < T.max_leaf) continue;
+            if (sz / nc < T.max_leaf) return;
             std::vector<int> saved(T.perm.begin() + off, T.perm.begin() + off + sz);
             double c[3] = {T.cx[id], T.cy[id], T.cz[id]};
-            s.sizes = split_range(T, a.weights, off, sz, c, nc, a.strategy);
+            s.sizes = split_range(T, a.weights, off, sz, c, nc, a.strategy, !wide_level);
             bool small = false;
             for (int v : s.sizes)
                 if (v < T.max_leaf) small = true;
             if (small) {
                 std::copy(saved.begin(), saved.end(), T.perm.begin() + off);
-                continue;
+                return;
             }
             s.ok = true;
             int o = off;
@@ -262,6 +273,13 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
                 s.geo.push_back(compute_geometry(T, a.radii, a.weights, o, v));
                 o += v;
             }
+        };
+        // (an `omp parallel for if(false)` would still count as an active level and serialise the sorts inside)
+        if (wide_level) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (long q = 0; q < (long)level.size(); q++) split_node(q);
+        } else {
+            for (long q = 0; q < (long)level.size(); q++) split_node(q);
         }
         std::vector<int> next;
         for (size_t q = 0; q < level.size(); q++) {
