@@ -289,3 +289,26 @@ def test_block_tree_queues_one_triangle(oracle):
     assert (len(a1), len(d1)) == (len(a), len(d))   # ... which is the default, as in the reference
     a2, d2 = Htool.block_tree_queues(cl, cl, 10.0, symmetry="S", UPLO="L", one_triangle=False)
     assert len(a2) > len(a) and len(d2) > len(d)    # both triangles on request
+
+
+def test_one_triangle_eligibility_of_separately_built_trees(built):
+    """Two cluster trees built alike on the same points count as one tree for symmetric storage (the reference's
+    example builds target and source clusters separately); a different tree on the same points does not."""
+    import Htool
+
+    pts = np.random.RandomState(3).rand(3, 3000)
+
+    def tree(leaf):
+        b = Htool.ClusterTreeBuilder()
+        b.set_maximal_leaf_size(leaf)
+        return b.create_cluster_tree(pts, 2, size_of_partition=1)
+
+    t1, t2, other = tree(20), tree(20), tree(45)
+    a_same, d_same = Htool.block_tree_queues(t1, t1, 10.0, symmetry="S", UPLO="L")
+    a_twin, d_twin = Htool.block_tree_queues(t1, t2, 10.0, symmetry="S", UPLO="L")
+    assert np.array_equal(a_same, a_twin) and np.array_equal(d_same, d_twin)
+    a_full, d_full = Htool.block_tree_queues(t1, t1, 10.0, symmetry="S", UPLO="L", one_triangle=False)
+    assert len(a_full) > len(a_same) and len(d_full) > len(d_same)
+    a_other, d_other = Htool.block_tree_queues(t1, other, 10.0, symmetry="S", UPLO="L")
+    a_plain, d_plain = Htool.block_tree_queues(t1, other, 10.0)
+    assert np.array_equal(a_other, a_plain) and np.array_equal(d_other, d_plain)   # not eligible: every block is kept
