@@ -38,3 +38,25 @@ def usable_cpus():
     except Exception:
         pass
     return max(1, n)
+
+
+def gmres_shift(apply, n, dtype, fraction=None, power_its=6, seed=3):
+    """Diagonal shift of the GMRES workloads (BASELINE config 5): a fixed fraction of the operator norm, estimated with a
+    few power iterations of `apply` (device tensors), so that the shifted system (shift I + A) is well posed but not
+    trivial -- the Krylov method needs its iterations.  Returns (shift, norm estimate)."""
+    import torch
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    v = torch.rand(n, dtype=torch.float64, generator=g).to(dtype).cuda()
+    lam = 0.0
+    for _ in range(power_its):
+        v = v / torch.linalg.norm(v)
+        w = apply(v)
+        lam = float(torch.linalg.norm(w))
+        v = w
+    return (GMRES_SHIFT_FRACTION if fraction is None else fraction) * lam, lam
+
+
+# fraction of |A| used as the diagonal shift of the GMRES workloads: tuned on the 500 000-point Laplace operator so that
+# the relative residual 1e-6 is reached in 35-50 iterations (see profiles/r02_gmres_shift_scan.json)
+GMRES_SHIFT_FRACTION = 3e-3

@@ -133,3 +133,87 @@ class CustomLocalToLocalOperator(Htool.VirtualLocalToLocalOperator):
     def local_add_matrix_product_row_major(self, trans, alpha, input, beta, output):
         output *= beta
         output += alpha * (self.data if trans == "N" else self.data.T) @ input
+
+
+def independent_leaf_checks(hmatrix, points_t, points_s, kind, p0, eps, n_sample=200, seed=0, max_block=600, transpose_rule=True, min_leaves=50):
+    """Independent (numpy, oracle/independent.py) checks of the low-rank leaves of a built H-matrix, none of which goes
+    through the C++ oracle: for a random sample of admissible leaves
+      * rank vs the explicit-residual ACA of the exact block (same pivots => same rank, +-1 on borderline leaves),
+      * rank <= SVD-rank(eps / 10) + 2 (the reference's reading of epsilon, define_custom_low_rank_generator.py:16-27),
+      * |A - U V|_F / |A|_F against eps (partial pivoting stops on a heuristic: most leaves within 3 eps, all within 10).
+    Returns a dict of the statistics that were asserted."""
+    from oracle import independent as I
+
+    L = np.asarray(hmatrix.leaves()).astype(np.int64)
+    pt = np.asarray(hmatrix.get_target_cluster().get_permutation())
+    ps = np.asarray(hmatrix.get_source_cluster().get_permutation())
+    cand = np.flatnonzero((L[:, 4] > 0) & (L[:, 1] <= max_block) & (L[:, 3] <= max_block))
+    rng = np.random.RandomState(seed)
+    pick = rng.choice(cand, min(n_sample, len(cand)), replace=False)
+    same = pm1 = 0
+    errs, over_svd, e2, a2 = [], [], 0.0, 0.0
+    for i in pick:
+        t_off, m, s_off, n, r = L[i]
+        A = O.kernel_block(kind, points_t[:, pt[t_off:t_off + m]], points_s[:, ps[s_off:s_off + n]], p0)
+        U, V = hmatrix.leaf_panels(int(i))
+        U, V = np.asarray(U), np.asarray(V)
+        assert U.shape == (m, r) and V.shape == (r, n)
+        ref = I.aca_full_residual(A, eps, transpose_role=transpose_rule and t_off > s_off)
+        assert ref is not None, "the explicit-residual ACA rejects a leaf the engine stored as low rank"
+        same += ref[0].shape[1] == r
+        pm1 += abs(ref[0].shape[1] - r) <= 1
+        err, _, rs = I.leaf_quality(A, U, V, eps)
+        errs.append(err / eps)
+        over_svd.append(r - rs)
+        e2 += np.linalg.norm(A - U @ V) ** 2
+        a2 += np.linalg.norm(A) ** 2
+    errs, over_svd = np.array(errs), np.array(over_svd)
+    k = len(pick)
+    stats = {"leaves": k, "same_rank": same / k, "within_one": pm1 / k, "err_over_eps_max": float(errs.max()), "err_over_eps_p90": float(np.percentile(errs, 90)),
+             "rank_minus_svd_rank_max": int(over_svd.max()), "aggregate_err_over_eps": float(np.sqrt(e2 / a2) / eps)}
+    assert k >= min(n_sample, min_leaves), f"only {k} admissible leaves to sample"
+    assert stats["same_rank"] >= 0.97 and stats["within_one"] == 1.0, stats
+    assert np.mean(over_svd <= 2) >= 0.99 and over_svd.max() <= 4, stats
+    assert np.mean(errs <= 3.0) >= 0.9 and errs.max() <= 10.0 and stats["aggregate_err_over_eps"] <= 2.0, stats
+    return stats
+
+
+def single_leaf_product_checks(hmatrix, cluster_t, cluster_s, dtype, n_sources=3, n_targets=12, seed=0, max_leaf_elements=4e7, row_window=None):
+    """CPU leaf loop on a sampled subset of the device's OWN panels, isolated through the tiling property: with x supported
+    on one source cluster leaf s, the rows of a target cluster leaf t receive the contribution of exactly ONE H-matrix leaf
+    (the one containing t x s), so   y[t] == U[t, :] (V[:, s] x_s)   (or D[t, s] x_s) on that leaf's downloaded panels.
+    Works at any size (one device product per source leaf).  row_window = (offset, size): operator built on a partition,
+    whose host product returns its local rows in cluster order.  Returns the number of (t, s) pairs compared."""
+    L = np.asarray(hmatrix.leaves()).astype(np.int64)
+    ti, _ = cluster_t._nodes()
+    si, _ = cluster_s._nodes()
+    pt, ps = np.asarray(cluster_t.get_permutation()), np.asarray(cluster_s.get_permutation())
+    r_off, r_size = row_window if row_window is not None else (0, len(pt))
+    tl = np.array([(o, s) for o, s, _, _, _, nc, _ in ti if nc == 0 and r_off <= o < r_off + r_size])
+    sl = np.array([(o, s) for o, s, _, _, _, nc, _ in si if nc == 0])
+    rng = np.random.RandomState(seed)
+    n_src = len(ps)
+    done = 0
+    for so, ss in sl[rng.choice(len(sl), n_sources, replace=False)]:
+        xs = rng.rand(ss) + (1j * rng.rand(ss) if np.dtype(dtype).kind == "c" else 0)
+        x = np.zeros(n_src, dtype=dtype)
+        x[ps[so:so + ss]] = xs
+        y = hmatrix * x
+        scale = np.abs(y).max()
+        for to, ts in tl[rng.choice(len(tl), n_targets, replace=False)]:
+            hit = np.flatnonzero((L[:, 0] <= to) & (to + ts <= L[:, 0] + L[:, 1]) & (L[:, 2] <= so) & (so + ss <= L[:, 2] + L[:, 3]))
+            assert len(hit) == 1, "the leaves do not tile the matrix"
+            t_off, m, s_off, n, r = L[hit[0]]
+            if (m * n if r < 0 else r * (m + n)) > max_leaf_elements:
+                continue
+            A, B = hmatrix.leaf_panels(int(hit[0]))
+            A = np.asarray(A)
+            if r < 0:
+                expect = A[to - t_off:to - t_off + ts, so - s_off:so - s_off + ss] @ xs
+            else:
+                expect = A[to - t_off:to - t_off + ts, :] @ (np.asarray(B)[:, so - s_off:so - s_off + ss] @ xs)
+            got = y[to - r_off:to - r_off + ts] if row_window is not None else y[pt[to:to + ts]]
+            assert np.abs(got - expect).max() <= 1e-12 * scale + 1e-300, (to, so, r, np.abs(got - expect).max(), scale)
+            done += 1
+    assert done >= n_sources * n_targets // 2
+    return done

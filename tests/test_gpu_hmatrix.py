@@ -121,10 +121,11 @@ def test_product_vs_cpu_leaf_loop_and_dense(built, oracle, n, leaf, eta, epsilon
 
 
 def test_rectangular_and_host_aca_ranks_match_oracle(built, oracle):
-    """400 x 200 operator (tests/test_distributed_operator.py:25 shape); host-driven ACA (callback
-    generator) must reproduce the oracle's ranks leaf by leaf: same algorithm, same pivots."""
+    """400 x 200 operator (tests/test_distributed_operator.py:25 shape); host-driven ACA (callback generator): every
+    sampled low-rank leaf against the independent numpy formulation (explicit-residual ACA, SVD epsilon-rank, Frobenius
+    error of U V against the exact block -- oracle/independent.py), then leaf-by-leaf rank equality with the C++ oracle."""
     import Htool
-    from tests.helpers import NumpyGenerator, cluster_of
+    from tests.helpers import NumpyGenerator, cluster_of, independent_leaf_checks
 
     O = oracle
     np.random.seed(0)
@@ -138,6 +139,7 @@ def test_rectangular_and_host_aca_ranks_match_oracle(built, oracle):
         y = H * x
         ye = gen.mat_vec(x)
         assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < epsilon
+        independent_leaf_checks(H, T, S, O.K_INV_DELTA, 0.1, epsilon, n_sample=200, transpose_rule=True)
         otc, osc = O.Cluster(T, max_leaf=10), O.Cluster(S, max_leaf=10)
         assert np.array_equal(otc.perm, np.asarray(tcl.get_permutation()))
         assert np.array_equal(osc.perm, np.asarray(scl.get_permutation()))

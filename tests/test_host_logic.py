@@ -104,7 +104,12 @@ def test_cluster_tree_invariants_and_oracle_equality(built, oracle, dimension, p
             sub = cl.get_cluster_on_partition(p)
             idx = perm[sub.get_offset():sub.get_offset() + sub.get_size()]
             assert np.all(pts[0, idx] == p)
-    # oracle equality
+    # independent property check (numpy eigh split direction, centre / radius from their definitions; oracle/independent.py)
+    from oracle import independent as I
+
+    ints, dbl = cl._nodes()
+    I.check_cluster_tree(ints, dbl, perm, pts, children, 10, 0, given_partition=partition_type != "None")
+    # and node-for-node equality with the C++ oracle (a second implementation of the same recurrence)
     oc = O.Cluster(pts, n_children=children, size_of_partition=world, partition=part, partition_is_local=is_local, max_leaf=10)
     assert np.array_equal(oc.perm, perm)
     ints, dbl = cl._nodes()
@@ -133,6 +138,10 @@ def test_partitioning_strategies(built, oracle, strategy_name):
     oc = O.Cluster(pts, size_of_partition=2, strategy=sid)
     assert np.array_equal(oc.perm, np.asarray(cl.get_permutation()))
     assert sorted(np.asarray(cl.get_permutation()).tolist()) == list(range(800))
+    from oracle import independent as I
+
+    ints, dbl = cl._nodes()
+    assert I.check_cluster_tree(ints, dbl, np.asarray(cl.get_permutation()), pts, 2, 10, sid) >= 10
 
 
 def test_radii_and_weights(built, oracle):
@@ -146,6 +155,9 @@ def test_radii_and_weights(built, oracle):
     assert np.array_equal(oc.perm, np.asarray(cl.get_permutation()))
     ints, dbl = cl._nodes()
     assert np.isclose(dbl[0, 3], oc.dnodes[0, 3])
+    from oracle import independent as I
+
+    assert I.check_cluster_tree(ints, dbl, np.asarray(cl.get_permutation()), pts, 2, 10, 0, radii, weights) >= 5
 
 
 def test_wrong_partition_format_raises(built):
