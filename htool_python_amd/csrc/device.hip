@@ -25,10 +25,12 @@
 #include <cstring>
 #include <mutex>
 #include <numeric>
+#include <type_traits>
 
 namespace hm {
 
 #include "product_kernels.inc"
+#include "product_mfma.inc"
 #include "pack_kernels.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -206,6 +208,56 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     D->rhs_cap = nr;
 }
 
+// ---- sixteen right-hand sides per sweep on the matrix cores (real operators, both triangles stored) ----
+static void ensure_w16(DeviceHMatrix *D) {
+    if (D->W16) return;
+    void *w = nullptr;
+    HIP_OK(dev_malloc(&w, (size_t)D->W_elems * 16 * sizeof(double)));
+    HIP_OK(hipMemset(w, 0, (size_t)D->W_elems * 16 * sizeof(double)));
+    // the partial sums phase A2 reduces, as index ranges of the coefficient workspace (read back from the A2 tables)
+    std::vector<Reduce16> items;
+    if (D->nA2) {
+        std::vector<GTile> t((size_t)D->nA2);
+        HIP_OK(hipMemcpy(t.data(), D->tilesA2, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
+        for (const GTile &x : t) {
+            GSeg sg;
+            HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
+            Reduce16 r;
+            r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)sizeof(double);
+            r.out_base = x.out_begin;
+            r.ld = sg.ld_last; r.nrows = sg.nrows_t; r.ncols = sg.ncols; r.pad_ = 0;
+            items.push_back(r);
+        }
+    }
+    D->red16 = upload(items);
+    D->n_red16 = (int)items.size();
+    D->W16 = w;
+}
+
+static void launch_sweep16(DeviceHMatrix *D, const double *x, long long x_stride, double *y, long long y_stride, int nr, int numbering, hipStream_t st) {
+    double *W16 = (double *)D->W16;
+    const int Ns = D->n_source;
+    const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
+    hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
+    const bool timing = D->phase_timing;
+    if (timing) HIP_OK(hipEventRecord(ev[0], st));
+    if (Ns) hipLaunchKernelGGL(gather_x16_kernel, dim3((unsigned)(((long long)Ns * 16 + 255) / 256)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_s : (const int *)nullptr, W16, Ns, nr);
+    if (timing) HIP_OK(hipEventRecord(ev[1], st));
+    if (D->nA) hipLaunchKernelGGL(tile_gemm_tall16, dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, W16);
+    if (timing) HIP_OK(hipEventRecord(ev[2], st));
+    if (D->n_red16) hipLaunchKernelGGL(reduce_partials16_kernel, dim3(D->n_red16), dim3(256), 0, st, (const Reduce16 *)D->red16, W16);
+    if (timing) HIP_OK(hipEventRecord(ev[3], st));
+    if (D->nB) hipLaunchKernelGGL(tile_gemm_wide16, dim3(D->nB), dim3(256), 0, st, out_user ? D->tilesB_user : D->tilesB_cluster, D->segs, (const double *)W16, y, y_stride, nr);
+    if (timing) HIP_OK(hipEventRecord(ev[4], st));
+    HIP_OK(hipGetLastError());
+    if (timing) D->nprod++;
+}
+
+static bool mfma_sweep_enabled() {
+    const char *v = getenv("HTOOL_MULTI_RHS_KERNEL"); // "valu": the 8-wide VALU sweeps for every count (A/B comparisons, tests)
+    return !(v && std::string(v) == "valu");
+}
+
 template <typename Ops>
 static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, hipStream_t st) {
     typedef typename Ops::T T;
@@ -219,6 +271,14 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
             else if (left >= 2) { launch_sweep<Ops, 2>(D, x, x_stride, y, y_stride, numbering, st); done += 2; }
             else { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; }
             continue;
+        }
+        if constexpr (std::is_same<Ops, RealOps>::value) {
+            if (left > 8 && D->W16) { // one sweep of the panels for up to 16 right-hand sides, on the matrix cores
+                const int nr = std::min(left, 16);
+                launch_sweep16(D, (const double *)x, x_stride, (double *)y, y_stride, nr, numbering, st);
+                done += nr;
+                continue;
+            }
         }
         if (left >= 8) { launch_sweep<Ops, 8>(D, x, x_stride, y, y_stride, numbering, st); done += 8; }
         else if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
@@ -234,6 +294,10 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
     const int need = D->one_triangle ? (mu >= 4 ? 4 : mu >= 2 ? 2 : 1) : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
+    if (mu > 8 && !D->is_complex && !D->one_triangle && !D->W16 && mfma_sweep_enabled()) {
+        HIP_OK(hipStreamSynchronize(st));
+        ensure_w16(D);
+    }
     if (need > D->rhs_cap) {
         HIP_OK(hipStreamSynchronize(st));
         if (D->is_complex) ensure_rhs_capacity<double2>(D, need);
@@ -340,7 +404,7 @@ void device_free(DeviceHMatrix *D) {
         if (B.zidxB) (void)hipFree(B.zidxB);
         if (B.tidxA) (void)hipFree(B.tidxA);
     }
-    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl})
+    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
                     (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord, (void *)D->tilesB_split, D->ypart})
@@ -360,6 +424,8 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     dst.dev = D;
     D->stream = nullptr;
     D->nprod = 0;
+    D->W16 = D->red16 = nullptr; // (created again by the copy's first 16-wide product)
+    D->n_red16 = 0;
     HIP_OK(hipStreamCreate(&D->stream));
     for (auto &slot : D->pev) for (auto &e : slot) { e = nullptr; HIP_OK(hipEventCreate(&e)); }
     auto dup = [](const void *p, size_t bytes) -> void * {

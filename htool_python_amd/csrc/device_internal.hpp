@@ -92,6 +92,11 @@ struct DeviceHMatrix {
     void *ypart = nullptr;
     long long ypart_stride = 0;
     int *perm_s = nullptr, *perm_t = nullptr, *iota = nullptr, *ones_idx = nullptr;
+    // 16-wide sweeps on the matrix cores (product_mfma.inc): coefficient workspace W16[index][16] and the list of partial
+    // sums to reduce between phase A and phase B; both created by the first product that needs them
+    void *W16 = nullptr;
+    void *red16 = nullptr;
+    int n_red16 = 0;
     void *W = nullptr;
     long long W_elems = 0;   // elements of ONE coefficient workspace; W holds rhs_cap of them back to back
     int rhs_cap = 0;

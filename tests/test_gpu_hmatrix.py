@@ -188,8 +188,9 @@ def test_custom_dense_blocks_generator(built, oracle):
 
 @pytest.mark.parametrize("complex_", [False, True])
 def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
-    """H @ X multiplies up to 8 right-hand sides per sweep of the panels (src/htool/hmatrix/hmatrix.hpp:119-138);
-    every column must equal the single-vector product bit for bit (same summation order), for any mu."""
+    """H @ X (src/htool/hmatrix/hmatrix.hpp:119-138) multiplies up to 8 right-hand sides per VALU sweep of the panels --
+    every column then equals the single-vector product bit for bit (same summation order) -- and, for real operators with
+    more than 8 columns, 16 per sweep on the matrix cores (v_mfma_f64_16x16x4_f64: other summation order, <= 1e-13)."""
     import Htool
     from tests.helpers import cluster_of
 
@@ -202,17 +203,90 @@ def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
         H = Htool.ComplexHMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.ComplexNativeGenerator("helmholtz", pts, pts, 6.0), cl, cl)
     else:
         H = Htool.HMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts), cl, cl)
-    for mu in (1, 2, 3, 5, 8, 11, 16):
+    for mu in (1, 2, 3, 5, 8, 11, 16, 21):
         X = np.random.rand(n, mu) + (1j * np.random.rand(n, mu) if complex_ else 0)
         X = np.asfortranarray(X)
         Y = H @ X
         assert Y.shape == (n, mu) and Y.flags.f_contiguous
+        mfma = mu > 8 and not complex_
         for c in range(mu):
-            assert np.array_equal(Y[:, c], H * np.ascontiguousarray(X[:, c]))
+            yc = H * np.ascontiguousarray(X[:, c])
+            if mfma and c < (mu // 16) * 16 + (16 if mu % 16 > 8 else 0):
+                assert np.linalg.norm(Y[:, c] - yc) <= 1e-13 * np.linalg.norm(yc)
+            else:
+                assert np.array_equal(Y[:, c], yc)
+        if mfma:
+            assert np.array_equal(Y, H @ X)  # bitwise repeatable
+            # a column's result does not depend on its neighbours or on their number
+            X2 = np.asfortranarray(np.random.rand(n, 12))
+            X2[:, 3] = X[:, 3]
+            assert np.array_equal((H @ X2)[:, 3], Y[:, 3])
     Ye = O.dense_matvec(O.K_HELMHOLTZ if complex_ else O.K_LAPLACE, pts, pts, X, 6.0 if complex_ else 0.0)
     assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-4
     with pytest.raises(RuntimeError, match="Wrong size for HMatrix-matrix product"):
         H @ np.zeros((n + 1, 2), order="F")
+
+
+@pytest.mark.parametrize("case", ["leaf10", "leaf48", "leaf100", "rect", "partition", "copy", "recompressed"])
+def test_sixteen_wide_mfma_sweep(built, oracle, case):
+    """The 16-wide sweep on the matrix cores against the single-vector products (<= 1e-13 relative, column by column) and the
+    exact dense operator, over the shapes its row-group / column-share logic distinguishes: row tiles of <= 32, <= 64 and
+    <= 128 rows, rectangular operators, operators built on one partition (cluster-numbered device path), deep copies and
+    recompressed operators (the 16-wide workspace is rebuilt)."""
+    import copy
+
+    import torch
+
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    np.random.seed(3)
+    leaf = {"leaf10": 10, "leaf48": 48}.get(case, 100)
+    n = 6000 if leaf == 100 else 3000
+    T = O.points_in_sphere(n)
+    S = O.points_in_sphere(2500) + np.array([[0.4], [0.0], [0.0]]) if case == "rect" else T
+    world = 3 if case == "partition" else 1
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    tcl = b.create_cluster_tree(T, 2, size_of_partition=world)
+    scl = tcl if S is T else cluster_of(S, leaf)
+    gen = Htool.NativeGenerator("laplace", T, S)
+    H = Htool.HMatrixTreeBuilder(1e-5, 10.0, "N", "N").build(gen, tcl, scl, 1 if case == "partition" else -1)
+    if case == "copy":
+        H0 = H
+        X0 = np.asfortranarray(np.random.rand(S.shape[1], 16))
+        Y0 = H0 @ X0
+        H = copy.deepcopy(H0)
+        del H0
+        assert np.array_equal(H @ X0, Y0)
+    if case == "recompressed":
+        X0 = np.asfortranarray(np.random.rand(S.shape[1], 16))
+        Y0 = H @ X0
+        assert Htool.recompression(H) > 0
+        Y1 = H @ X0
+        assert np.linalg.norm(Y1 - Y0) / np.linalg.norm(Y0) < 1e-4 and not np.array_equal(Y1, Y0)
+    ns = S.shape[1]
+    for mu in (9, 16, 35):
+        X = np.asfortranarray(np.random.rand(ns, mu))
+        Y = H @ X
+        for c in range(mu):
+            yc = H * np.ascontiguousarray(X[:, c])
+            assert np.linalg.norm(Y[:, c] - yc) <= 1e-13 * np.linalg.norm(yc), (case, mu, c)
+        if case != "partition":
+            Ye = O.dense_matvec(O.K_LAPLACE, T, S, X)
+            assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-5
+    if case == "partition":  # the multi-GPU path: cluster-numbered x in, the local row slice out, on device buffers
+        sub = tcl.get_cluster_on_partition(1)
+        perm = np.asarray(tcl.get_permutation())
+        Xd = torch.from_numpy(np.ascontiguousarray(X[perm].T)).cuda()  # mu x n, cluster numbering
+        Yd = torch.zeros(mu, sub.get_size(), dtype=torch.float64, device="cuda")
+        H.matmat_device(Xd.data_ptr(), ns, Yd.data_ptr(), sub.get_size(), mu, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(Yd.cpu().numpy().T, Y)
+        rows = perm[sub.get_offset():sub.get_offset() + sub.get_size()]
+        Ye = O.dense_matvec(O.K_LAPLACE, T, S, X, rows=rows)
+        assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-5
 
 
 @pytest.mark.parametrize("complex_", [False, True])

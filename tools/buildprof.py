@@ -1,4 +1,5 @@
-import logging, time, sys
+import logging, os, time, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 logging.basicConfig(level=logging.DEBUG, stream=sys.stderr)
 import numpy as np, torch, Htool
 from htool_python_amd.workloads import points_in_sphere
