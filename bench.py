@@ -28,42 +28,86 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md; measured copy ceiling 6290)
 
 
+def kernel_source_sha1():
+    """Fingerprint of the product kernels' source: committed PMC measurements are only quoted for the code they were taken on."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for name in ("product_kernels.inc", "device_tables.inc"):
+        with open(os.path.join(ROOT, "htool_python_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(args, n):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-    same command line (profiles/), or None when no pass exists for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_1m_laplace.json")
-    if not (os.path.exists(path) and n == 1_000_000 and args.kernel == "laplace" and args.eps == 1e-3 and args.eta == 10.0 and args.leaf == 100 and args.gpus == 1):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command line
+    (profiles/), or None when no pass exists for this workload OR the kernels have changed since the passes were taken
+    (the file records the fingerprint of the kernel source it was measured on)."""
+    if not (n == 1_000_000 and args.kernel == "laplace" and args.eps == 1e-3 and args.eta == 10.0 and args.leaf == 100 and args.gpus == 1 and args.rhs == 1):
         return None
-    with open(path) as f:
-        return json.load(f).get("tile_gemv_wide_hbm_bytes_per_launch")
+    for name in ("r02_pmc_hbm_traffic_1m_laplace.json", "r01_pmc_hbm_traffic_1m_laplace.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha1") == kernel_source_sha1():
+            return d.get("tile_gemv_wide_hbm_bytes_per_launch")
+    return None
 
 
-def cpu_build_sample(n_sample=150_000):
-    """Build seconds, CPU oracle (OpenMP) vs this engine, on the same bounded instance: the first n_sample points of
-    the seeded cloud (a uniform sample of the ball), same kernel / eps / eta / leaf size as the bench workload."""
+def cpu_full_operator(n_points=100_000, eps=1e-4, eta=10.0, leaf=100, budget_s=8.0):
+    """BASELINE config C2 (100 000-point Laplace, eps 1e-4: the whole operator fits the host, 8 GB): WHOLE build and WHOLE
+    product on the CPU (oracle/hmat_oracle.cpp, OpenMP over blocks / leaves) next to this engine on the same instance."""
     import numpy as np
+    import torch
 
     import Htool
-    from htool_python_amd.workloads import points_in_sphere
+    from htool_python_amd.workloads import algorithmic_bytes, points_in_sphere
     from oracle import oracle as O
 
-    a = cpu_build_sample.args
-    if a.kernel != "laplace":
-        return None
-    pts = np.ascontiguousarray(points_in_sphere(a.n, seed=0)[:, :n_sample])
+    pts = points_in_sphere(n_points, seed=0)
     t0 = time.perf_counter()
-    oc = O.Cluster(pts, max_leaf=a.leaf)
-    OH = O.HMatrix(oc, oc, O.K_LAPLACE, eps=a.eps, eta=a.eta)
-    t_cpu = time.perf_counter() - t0
+    oc = O.Cluster(pts, max_leaf=leaf)
+    OH = O.HMatrix(oc, oc, O.K_LAPLACE, eps=eps, eta=eta)
+    t_cpu_build = time.perf_counter() - t0
+    x = np.random.RandomState(0).rand(n_points)
+    t_all = []
+    t_start = time.time()
+    while len(t_all) < 3 or (time.time() - t_start < budget_s and len(t_all) < 20):
+        t0 = time.perf_counter()
+        y_cpu = OH.matvec(x)
+        t_all.append(time.perf_counter() - t0)
+    t_cpu = sorted(t_all)[len(t_all) // 2]
+    ab_cpu = algorithmic_bytes(OH.leaves, n_points, n_points, 8)["total"]
     t0 = time.perf_counter()
     cb = Htool.ClusterTreeBuilder()
-    cb.set_maximal_leaf_size(a.leaf)
+    cb.set_maximal_leaf_size(leaf)
     cl = cb.create_cluster_tree(pts, 2)
-    Hs = Htool.HMatrixTreeBuilder(a.eps, a.eta, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts), cl, cl)
-    t_gpu = time.perf_counter() - t0
-    same = len(OH.leaves) == len(Hs.leaves())
-    return {"points": n_sample, "cpu_oracle_s": t_cpu, "gpu_s": t_gpu, "threads": O.num_threads(), "same_leaf_count": bool(same),
-            "note": "cluster tree + block tree + ACA + dense fill; oracle/hmat_oracle.cpp with OpenMP vs this engine (host trees, device ACA)"}
+    Hs = Htool.HMatrixTreeBuilder(eps, eta, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts), cl, cl)
+    torch.cuda.synchronize()
+    t_gpu_build = time.perf_counter() - t0
+    gpu_leaves = Hs.leaves()
+    ab_gpu = algorithmic_bytes(gpu_leaves, n_points, n_points, 8)["total"]
+    xd, yd = torch.from_numpy(x).cuda(), torch.zeros(n_points, dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        Hs.matvec_device(xd.data_ptr(), yd.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        Hs.matvec_device(xd.data_ptr(), yd.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    t_gpu = (time.perf_counter() - t0) / 20
+    y_gpu = yd.cpu().numpy()
+    del Hs
+    Htool.release_workspace()
+    return {"workload": f"BASELINE C2: {n_points}-point 3D Laplace, eps={eps:g}, eta={eta:g}, leaf={leaf} -- the whole operator, whole build, on the CPU",
+            "cpu_build_s": t_cpu_build, "cpu_matvec_GBps": ab_cpu / t_cpu / 1e9, "cpu_matvec_ms": t_cpu * 1e3, "cpu_algorithmic_GB": ab_cpu / 1e9,
+            "threads": O.num_threads(), "passes": len(t_all),
+            "gpu_build_s": t_gpu_build, "gpu_matvec_GBps": ab_gpu / t_gpu / 1e9, "gpu_matvec_ms": t_gpu * 1e3,
+            "same_leaf_count": bool(len(OH.leaves) == len(gpu_leaves)),
+            "rel_diff_cpu_gpu_product": float(np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu))}
 
 
 def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
@@ -103,9 +147,9 @@ def cpu_baseline(H, leaves, n_rows, n_source, elem_bytes, budget_s=12.0):
         t_all.append(time.perf_counter() - t0)
         reps += 1
     t_med = sorted(t_all)[len(t_all) // 2]
-    build = cpu_build_sample()
+    del panels
     return {
-        "build_sample": build,
+        "full_operator": cpu_full_operator(),
         "value": tot / t_med / 1e9,
         "unit": "GB/s",
         "cores": O.num_threads(),
@@ -141,9 +185,8 @@ def main():
     ap.add_argument("--symmetric", choices=["full", "one-triangle"], default=None,
                     help="build with symmetry 'S' / UPLO 'L' (single GPU only): 'full' stores both triangles (the default engine "
                          "layout), 'one-triangle' stores the lower triangle only and uses every leaf twice in a fused sweep")
-    ap.add_argument("--check", action="store_true", help="also report the error against sampled exact rows")
+    ap.add_argument("--check", action="store_true", help="(kept for compatibility: the error against sampled exact rows is always reported)")
     args = ap.parse_args()
-    cpu_build_sample.args = args
     # stdout carries exactly ONE line (the JSON): libraries that chat on stdout (RCCL prints a version banner when a
     # communicator is created) are sent to stderr by pointing fd 1 at fd 2 until the result is ready
     sys.stdout.flush()
@@ -204,7 +247,24 @@ def main():
         builder.set_symmetric_storage(args.symmetric == "one-triangle")
     torch.cuda.synchronize()
     t0 = time.time()
-    H = builder.build(gen, cluster, cluster, rank if dist_mode else -1)
+    dist_op, rccl_error = None, None
+    if dist_mode and args.backend == "nccl":
+        # the reference's decomposition through its own entry point (DefaultApproximationBuilder, utility.hpp:26): rank p builds
+        # rows(partition p) x all columns; the communicator carries a library-owned RCCL handle, so the exchange of every
+        # product runs inside the library on device buffers (htool_distributed_matvec_device)
+        import mpi4py
+
+        comm = mpi4py.MPI.COMM_WORLD
+        rccl_error = None
+        try:
+            comm.use_rccl()
+        except Exception as e:  # reported in the JSON line ("exchange"); the exchange then goes through torch.distributed (also RCCL)
+            rccl_error = repr(e)
+        approx = Htool.DefaultApproximationBuilder(gen, cluster, cluster, builder, comm)
+        dist_op = approx.distributed_operator
+        H = approx.hmatrix
+    else:
+        H = builder.build(gen, cluster, cluster, rank if dist_mode else -1)
     torch.cuda.synchronize()
     t_build = time.time() - t0
     t_recompress = None
@@ -249,21 +309,31 @@ def main():
 
         gather = SliceGatherer(sizes, dtype, "cuda")
 
-        def step():
-            # exchange: every GPU contributes its slice of x (cluster numbering) -- RCCL all-gather over xGMI --
-            # then multiplies its rows
-            x_full = gather(x_local)
-            H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
+        if dist_op is not None and dist_op.has_rccl:
+            def step():
+                # one library call: RCCL all-gather of the x slices over xGMI + compaction + the local product, on one stream
+                dist_op.matvec_device(x_local.data_ptr(), y.data_ptr(), stream)
+        else:
+            def step():
+                # rehearsal path (gloo, ranks sharing a GPU): host-staged exchange, then the local product
+                x_full = gather(x_local)
+                H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
 
     gmres_info = None
     if args.gmres > 0:
         from htool_python_amd.krylov import gmres
         from htool_python_amd.solver import DeviceOperator
+        from htool_python_amd.workloads import gmres_shift
 
         part = [(cluster.get_cluster_on_partition(p).get_offset(), cluster.get_cluster_on_partition(p).get_size()) for p in range(world)] if dist_mode else None
-        shift = args.shift if args.shift != 0.0 else n / 50.0
-        op = DeviceOperator(H, part, rank, None, shift)
-        b_local = torch.rand(op.size, dtype=torch.float64, generator=gen_t).to(dtype).cuda()
+        plain = DeviceOperator(H, part, rank, None, 0.0, dist_op=dist_op)
+        if args.shift != 0.0:
+            shift, norm_est = args.shift, None
+        else:  # a fixed fraction of |A| (power iterations): well posed, but the Krylov method needs its iterations
+            shift, norm_est = gmres_shift(plain.apply, plain.size, dtype, reduce=plain.reduce if dist_mode else None)
+        op = DeviceOperator(H, part, rank, None, shift, dist_op=dist_op)
+        x_ref = torch.rand(op.size, dtype=torch.float64, generator=gen_t).to(dtype).cuda()
+        b_local = op.apply(x_ref)  # use_ddm_solver.py:60-61: b = A x_ref
         red = op.reduce if dist_mode else None
         args.steps = args.gmres
 
@@ -280,7 +350,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if step is None:
-        _, gmres_info = run_gmres()
+        xs_, gmres_info = run_gmres()
+        gmres_info["x"] = xs_
     else:
         for _ in range(args.steps):
             step()
@@ -292,22 +363,49 @@ def main():
     n_ph, ph = H.phase_times_us()
     exchange_us = None
     if dist_mode and step is not None:
-        # the exchange on its own (reported separately; it is inside the timed steps as well)
+        # the exchange on its own (reported separately; it is inside the timed steps as well): the same steps
+        # minus the same number of local products on an already gathered vector
+        x_full_once = gather(x_local).clone()
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            gather(x_local)
+            H.matvec_device(x_full_once.data_ptr(), y.data_ptr(), 1, stream)
         torch.cuda.synchronize()
-        exchange_us = (time.perf_counter() - t1) / args.steps * 1e6
+        local_only = (time.perf_counter() - t1) / args.steps
+        exchange_us = max(0.0, dt / args.steps - local_only) * 1e6
+        step()  # (y holds the distributed product again)
+        torch.cuda.synchronize()
 
     tot_bytes = float(ab["total"])
-    if args.check and dist_mode:
-        # distributed result vs exact rows: gather the y slices and the x slices on every rank
-        perm = np.asarray(cluster.get_permutation())
-        y_user, x_user = np.zeros(n, dtype=np.complex128 if is_complex else np.float64), np.zeros(n, dtype=np.complex128 if is_complex else np.float64)
-        y_user[perm] = SliceGatherer(sizes, dtype, "cuda")(y).cpu().numpy()
-        x_user[perm] = SliceGatherer(sizes, dtype, "cuda")(x_local).cpu().numpy()
+    # correctness figure of every run: the product against exact rows of the dense operator (256 sampled rows; column 0 when
+    # several right-hand sides are multiplied)
+    rel_err = None
+    if step is not None:
+        from oracle import oracle as O
+
+        kind = {"laplace": 1, "inv_delta": 0, "helmholtz": 2}[args.kernel]
+        if not dist_mode:
+            rows = np.arange(0, n, max(1, n // 256))
+            xx, yy = x.cpu().numpy(), y.cpu().numpy()
+            if args.rhs > 1:
+                xx, yy = xx[0], yy[0]
+            ye = O.dense_matvec(kind, pts, pts, xx, param, rows=rows)
+            rel_err = float(np.linalg.norm(yy[rows] - ye) / np.linalg.norm(ye))
+        else:
+            # every rank checks rows of its own partition against the exact operator applied to the gathered x
+            perm = np.asarray(cluster.get_permutation())
+            x_user = np.zeros(n, dtype=np.complex128 if is_complex else np.float64)
+            x_user[perm] = gather(x_local).cpu().numpy()
+            off = local.get_offset()
+            idx = np.arange(0, local.get_size(), max(1, local.get_size() // max(1, 256 // world)))
+            ye = O.dense_matvec(kind, pts, pts, x_user, param, rows=perm[off + idx])
+            dev = "cuda" if args.backend == "nccl" else "cpu"
+            e2 = torch.tensor([float(np.linalg.norm(y.cpu().numpy()[idx] - ye) ** 2), float(np.linalg.norm(ye) ** 2)], dtype=torch.float64, device=dev)
+            dist.all_reduce(e2)
+            rel_err = float(torch.sqrt(e2[0] / e2[1]))
+    elif gmres_info is not None:
+        pass  # (the GMRES mode reports its true residual below)
     per_rank = None
     if dist_mode:
         dev = "cuda" if args.backend == "nccl" else "cpu"
@@ -350,10 +448,29 @@ def main():
         "rhs_per_step": args.rhs,
         "symmetric_storage": args.symmetric,
         "per_rank": per_rank,   # multi-GPU: bytes, product time (sum of its kernels, HIP events) and exchange time of every rank
-        "gmres": None if gmres_info is None else {"iterations": gmres_info["iterations"], "s_per_iteration": dt / max(gmres_info["iterations"], 1),
-                                                   "relative_residuals": [gmres_info["residuals"][i] for i in (0, len(gmres_info["residuals"]) // 2, -1)],
-                                                   "note": "step = one GMRES iteration (1 product + CGS2 orthogonalisation) on (shift I + H), no preconditioner"},
+        "rel_err_sampled_rows": rel_err,
+        "exchange": None if not dist_mode else ("htool_distributed_matvec_device: ncclAllGather of the x slices + compaction + local product inside the library, one stream"
+                                                if dist_op is not None and dist_op.has_rccl else
+                                                (f"torch.distributed all_gather_into_tensor (RCCL) + local product; library communicator unavailable: {rccl_error}"
+                                                 if args.backend == "nccl" else "host-staged gloo all-gather (rehearsal)")),
     }
+    if gmres_info is not None:
+        # true residual and solution error of the timed solve (use_ddm_solver.py:60-61, tests/test_ddm_solver.py:659-660)
+        xs = gmres_info.pop("x")
+        res = gmres_info["residuals"]
+        r_true = b_local - op.apply(xs)
+        sq = torch.stack([torch.sum(torch.abs(r_true) ** 2), torch.sum(torch.abs(b_local) ** 2), torch.sum(torch.abs(xs - x_ref) ** 2), torch.sum(torch.abs(x_ref) ** 2)]).to(torch.float64)
+        if dist_mode:
+            op.reduce(sq)
+        sq = sq.cpu().numpy()
+        hit = [i + 1 for i, v in enumerate(res) if v <= 1e-6]
+        out["gmres"] = {"iterations": gmres_info["iterations"], "s_per_iteration": dt / max(gmres_info["iterations"], 1),
+                        "iterations_to_1e-6": hit[0] if hit else None,
+                        "relative_residuals": [res[i] for i in (0, len(res) // 2, -1)],
+                        "true_relative_residual": float(np.sqrt(sq[0] / sq[1])), "solution_error": float(np.sqrt(sq[2] / sq[3])),
+                        "shift": shift, "operator_norm_estimate": norm_est,
+                        "system": "(shift I + H) x = b with b = (shift I + H) x_ref, shift = 8e-3 |H| (power iterations): unpreconditioned GMRES needs ~40 iterations for 1e-6",
+                        "note": "step = one GMRES iteration (1 product + CGS2 orthogonalisation), restart = number of steps, device-resident Krylov vectors"}
     if rank == 0:
         t_b = ph[3] * 1e-6 if n_ph else None
         fused = args.symmetric == "one-triangle"
@@ -376,13 +493,6 @@ def main():
         }
         out["hmatrix"] = {"n_dense": stats["n_dense"], "n_low_rank": stats["n_low_rank"], "max_rank": stats["max_rank"],
                           "mean_rank": stats["sum_rank"] / max(stats["n_low_rank"], 1), "hbm_resident_GB": stats["hbm_bytes"] / 1e9}
-        if args.check:
-            from oracle import oracle as O
-
-            rows = np.arange(0, n, max(1, n // 256))
-            xx, yy = (x.cpu().numpy(), y.cpu().numpy()) if not dist_mode else (x_user, y_user)
-            ye = O.dense_matvec({"laplace": 1, "inv_delta": 0, "helmholtz": 2}[args.kernel], pts, pts, xx, param, rows=rows)
-            out["rel_err_sampled_rows"] = float(np.linalg.norm(yy[rows] - ye) / np.linalg.norm(ye))
         if world == 1 and not args.no_cpu_baseline and not is_complex:
             out["cpu_baseline"] = cpu_baseline(H, leaves, n, n, elem)
         sys.stdout.flush()

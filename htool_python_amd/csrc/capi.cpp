@@ -14,38 +14,10 @@
 
 using namespace hm;
 
-struct htool_cluster {}; // never instantiated: handles are hm::ClusterHandle
-struct htool_generator {
-    Generator g;
-};
-struct htool_hmatrix {
-    HMatrix H;
-    ClusterHandle *tch = nullptr, *sch = nullptr;
-    void *factor = nullptr; // DenseFactor of the host fallback for lu/cholesky (capi.cpp)
-    ~htool_hmatrix();
-};
-struct htool_distributed {
-    htool_hmatrix *hmat = nullptr;
-    htool_hmatrix *block_diag = nullptr; // (partition rank x partition rank) sub-operator; aliases hmat for one rank
-    htool_comm comm;
-    const ClusterTree *tc = nullptr, *sc = nullptr;
-    std::vector<int64_t> counts, displs; // rows per rank / first row per rank (cluster numbering)
-};
+#include "capi_internal.hpp"
 
 static thread_local std::string g_err;
-
-#define API_BEGIN try {
-#define API_END                                              \
-    }                                                        \
-    catch (const std::exception &e) {                        \
-        g_err = e.what();                                    \
-        return 1;                                            \
-    }                                                        \
-    catch (...) {                                            \
-        g_err = "unknown error";                             \
-        return 1;                                            \
-    }                                                        \
-    return 0;
+std::string &htool_error_slot() { return g_err; }
 
 static inline const ClusterHandle *CH(const htool_cluster *c) { return reinterpret_cast<const ClusterHandle *>(c); }
 
@@ -694,27 +666,48 @@ int htool_distributed_create_default(const htool_generator *g, const htool_clust
         d->counts.push_back(T->size[T->part_nodes[p]]);
         d->displs.push_back(T->offset[T->part_nodes[p]]);
     }
+    if ((int)d->sc->part_nodes.size() == comm->size) // the source tree carries a partition of the same size: the device path gathers x by it
+        for (int p = 0; p < comm->size; p++) {
+            d->s_counts.push_back(d->sc->size[d->sc->part_nodes[p]]);
+            d->s_displs.push_back(d->sc->offset[d->sc->part_nodes[p]]);
+        }
     const bool single = comm->size == 1 && T->part_nodes[0] == 0;
     d->hmat = build_hmatrix(g, target_root, source_root, params, single ? -1 : comm->rank);
     // block-diagonal part (distributed_operator/utility.hpp:31): needs the source tree to carry the same partition
     const ClusterTree *S = CH(source_root)->tree;
+    // It is built when first asked for (htool_distributed_block_diagonal_hmatrix): a solver without preconditioner, or a
+    // bare product loop, never needs this second copy of the diagonal block.  The generator and the clusters have to
+    // outlive the distributed operator, as they do in the reference (which stores references to them).
     if (single) d->block_diag = d->hmat;
     else if ((int)S->part_nodes.size() == comm->size) {
-        d->block_diag = build_hmatrix(g, target_root, source_root, params, comm->rank, comm->rank);
-        d->block_diag->H.local_numbering = true;
+        d->gen = g; d->t_root = target_root; d->s_root = source_root; d->params = *params;
+        d->block_diag_pending = true;
     }
     *out = d.release();
     API_END
 }
 void htool_distributed_destroy(htool_distributed *d) {
     if (d) {
+        dist_device_free(d->dev);
         if (d->block_diag != d->hmat) delete d->block_diag;
         delete d->hmat;
         delete d;
     }
 }
 htool_hmatrix *htool_distributed_hmatrix(htool_distributed *d) { return d->hmat; }
-htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *d) { return d->block_diag; }
+htool_hmatrix *htool_distributed_block_diagonal_hmatrix(htool_distributed *d) {
+    if (d->block_diag_pending) {
+        d->block_diag_pending = false;
+        try {
+            d->block_diag = build_hmatrix(d->gen, d->t_root, d->s_root, &d->params, d->comm.rank, d->comm.rank);
+            d->block_diag->H.local_numbering = true;
+        } catch (const std::exception &e) {
+            g_err = e.what();
+            d->block_diag = nullptr;
+        }
+    }
+    return d->block_diag;
+}
 void htool_distributed_shape(const htool_distributed *d, int *rows, int *cols) {
     *rows = d->tc->n_points;
     *cols = d->sc->n_points;

@@ -1,0 +1,52 @@
+// capi_internal.hpp -- the handle types behind include/htool_mi355x.h, shared by capi.cpp (g++) and dist_device.hip (hipcc)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/htool_mi355x.h"
+#include "hmatrix.hpp"
+
+struct htool_cluster {}; // never instantiated: handles are hm::ClusterHandle
+struct htool_generator {
+    hm::Generator g;
+};
+struct htool_hmatrix {
+    hm::HMatrix H;
+    hm::ClusterHandle *tch = nullptr, *sch = nullptr;
+    void *factor = nullptr; // DenseFactor of the host fallback for lu/cholesky (capi.cpp)
+    ~htool_hmatrix();
+};
+struct DistDeviceState; // device-side exchange buffers of a distributed operator (dist_device.hip)
+struct htool_distributed {
+    htool_hmatrix *hmat = nullptr;
+    htool_hmatrix *block_diag = nullptr; // (partition rank x partition rank) sub-operator; aliases hmat for one rank
+    htool_comm comm;
+    const hm::ClusterTree *tc = nullptr, *sc = nullptr;
+    std::vector<int64_t> counts, displs;     // rows per rank / first row per rank (cluster numbering, target tree)
+    std::vector<int64_t> s_counts, s_displs; // the same for the source tree's partition (empty: it has none of this size)
+    DistDeviceState *dev = nullptr;
+    // what the deferred build of block_diag needs (it is built when first asked for: utility.hpp:31)
+    const htool_generator *gen = nullptr;
+    const htool_cluster *t_root = nullptr, *s_root = nullptr;
+    htool_build_params params;
+    bool block_diag_pending = false;
+};
+
+// last error of the calling thread (htool_last_error); set by the API_END macro of every translation unit
+std::string &htool_error_slot();
+
+#define API_BEGIN try {
+#define API_END                                              \
+    }                                                        \
+    catch (const std::exception &e) {                        \
+        htool_error_slot() = e.what();                       \
+        return 1;                                            \
+    }                                                        \
+    catch (...) {                                            \
+        htool_error_slot() = "unknown error";                \
+        return 1;                                            \
+    }                                                        \
+    return 0;
+
+void dist_device_free(DistDeviceState *s); // dist_device.hip

@@ -1,0 +1,238 @@
+// dist_device.hip -- the exchange step of the row-distributed product, inside the library: RCCL over xGMI.
+//
+// Replaces the MPI_Allgatherv of htool::add_distributed_operator_vector_product_global_to_global
+// (src/htool/distributed_operator/distributed_operator.hpp:33,55; communicator caster src/htool/misc/wrapper_mpi.hpp:28-55).
+// One process per GPU; rank p owns the rows of partition p (DefaultApproximationBuilder, utility.hpp:26).  In a
+// GPU-resident loop every rank keeps only its slice of a vector, so the exchange is an all-gather of the x slices
+// BEFORE the product:
+//     ncclAllGather (zero-copy when all slices have the same length, on padded equal slices otherwise)
+//  -> one compaction kernel (padded slices -> the contiguous cluster-numbered x; not P copies)
+//  -> the local product in cluster numbering (device.hip), all on ONE stream: no host synchronisation in between.
+// The message is small (N s / P bytes per rank: 1 MB at N = 10^6, P = 8), so the step is latency-bound; RCCL runs
+// it as a direct exchange over the point-to-point xGMI links.
+// The communicator is created by the library from a unique id that the host language broadcasts (the NCCL bootstrap
+// pattern), or wraps one the caller already has.
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "capi_internal.hpp"
+#include "device_internal.hpp"
+
+using namespace hm;
+
+#define RCCL_OK(call)                                                                                                          \
+    do {                                                                                                                       \
+        ncclResult_t r_ = (call);                                                                                              \
+        if (r_ != ncclSuccess) throw hm::Error(hm::strprintf("RCCL error %s at %s:%d (%s)", ncclGetErrorString(r_), __FILE__, __LINE__, #call)); \
+    } while (0)
+
+namespace {
+
+struct RcclComm {
+    ncclComm_t comm = nullptr;
+    bool owned = true;
+    int rank = 0, size = 1, device = 0;
+    // staging buffers of the host-buffer exchange (htool_comm.allgatherv on an RCCL communicator)
+    void *h_send = nullptr, *h_recv = nullptr;
+    size_t h_cap = 0;
+    hipStream_t stream = nullptr;
+    ~RcclComm() {
+        if (h_send) (void)hipFree(h_send);
+        if (h_recv) (void)hipFree(h_recv);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (comm && owned) (void)ncclCommDestroy(comm);
+    }
+};
+
+// host-buffer all-gather on an RCCL communicator: staged through device buffers (used by the replicated-vector API)
+int rccl_host_allgatherv(void *ctx, const void *send, int64_t send_bytes, void *recv, const int64_t *recv_bytes, const int64_t *displs) {
+    RcclComm *c = static_cast<RcclComm *>(ctx);
+    try {
+        HIP_OK(hipSetDevice(c->device));
+        int64_t pad = 0;
+        for (int p = 0; p < c->size; p++) pad = std::max(pad, recv_bytes[p]);
+        pad = (pad + 15) / 16 * 16;
+        if ((size_t)pad > c->h_cap) {
+            if (c->h_send) (void)hipFree(c->h_send);
+            if (c->h_recv) (void)hipFree(c->h_recv);
+            c->h_send = c->h_recv = nullptr;
+            HIP_OK(hipMalloc(&c->h_send, (size_t)pad));
+            HIP_OK(hipMalloc(&c->h_recv, (size_t)pad * c->size));
+            c->h_cap = (size_t)pad;
+        }
+        if (!c->stream) HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_OK(hipMemcpyAsync(c->h_send, send, (size_t)send_bytes, hipMemcpyHostToDevice, c->stream));
+        RCCL_OK(ncclAllGather(c->h_send, c->h_recv, (size_t)pad, ncclUint8, c->comm, c->stream));
+        for (int p = 0; p < c->size; p++)
+            HIP_OK(hipMemcpyAsync((char *)recv + displs[p], (const char *)c->h_recv + (size_t)p * pad, (size_t)recv_bytes[p], hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    } catch (const std::exception &e) {
+        htool_error_slot() = e.what();
+        return 1;
+    }
+    return 0;
+}
+
+// gathered[p][c][0 : pad)  ->  x_full[c][displs[p] : displs[p] + counts[p])   (one launch for all ranks and columns)
+template <typename T>
+__global__ void compact_slices_kernel(const T *__restrict__ gathered, T *__restrict__ x_full, const int *__restrict__ counts, const int *__restrict__ displs, int pad, int mu,
+                                      long long ldx) {
+    const int p = blockIdx.y, c = blockIdx.z;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < counts[p]) x_full[(long long)c * ldx + displs[p] + i] = gathered[((long long)p * mu + c) * pad + i];
+}
+
+} // namespace
+
+struct DistDeviceState {
+    int device = 0;
+    void *send = nullptr, *recv = nullptr, *x_full = nullptr;
+    int *counts = nullptr, *displs = nullptr;
+    int pad = 0, mu_cap = 0;
+    bool equal = false;
+    ~DistDeviceState() {
+        (void)hipSetDevice(device);
+        for (void *p : {send, recv, x_full, (void *)counts, (void *)displs}) if (p) (void)hipFree(p);
+    }
+};
+void dist_device_free(DistDeviceState *s) { delete s; }
+
+static DistDeviceState *dist_state(htool_distributed *d, int mu) {
+    const HMatrix &H = d->hmat->H;
+    const size_t es = H.is_complex ? 16 : 8;
+    const int P = d->comm.size;
+    if (d->dev && d->dev->mu_cap >= mu) return d->dev;
+    HM_CHECK((int)d->s_counts.size() == P, "distributed device product: the source cluster tree carries no partition of the communicator's size");
+    std::unique_ptr<DistDeviceState> s(new DistDeviceState);
+    HIP_OK(hipGetDevice(&s->device));
+    std::vector<int> cnt(P), dsp(P);
+    int pad = 0;
+    bool equal = true;
+    for (int p = 0; p < P; p++) {
+        cnt[p] = (int)d->s_counts[p];
+        dsp[p] = (int)d->s_displs[p];
+        pad = std::max(pad, cnt[p]);
+        equal = equal && cnt[p] == cnt[0];
+    }
+    if (const char *f = getenv("HTOOL_DIST_FORCE_PADDED")) // tests: take the padded-slices path even for equal slices / one rank
+        if (f[0] == '1') equal = false;
+    s->pad = pad;
+    s->equal = equal;
+    s->mu_cap = mu;
+    const size_t ns = (size_t)d->sc->n_points;
+    HIP_OK(hipMalloc(&s->send, std::max<size_t>((size_t)pad * mu, 1) * es));
+    HIP_OK(hipMalloc(&s->recv, std::max<size_t>((size_t)pad * mu * P, 1) * es));
+    HIP_OK(hipMalloc(&s->x_full, std::max<size_t>(ns * mu, 1) * es));
+    HIP_OK(hipMalloc((void **)&s->counts, sizeof(int) * P));
+    HIP_OK(hipMalloc((void **)&s->displs, sizeof(int) * P));
+    HIP_OK(hipMemcpy(s->counts, cnt.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(s->displs, dsp.data(), sizeof(int) * P, hipMemcpyHostToDevice));
+    dist_device_free(d->dev);
+    d->dev = s.release();
+    return d->dev;
+}
+
+// Y_local = A[rows of this rank, :] X with X given by its local slices: column c of X_local holds this rank's part
+// (source partition `rank`, cluster numbering) at X_local + c * ldx; Y_local + c * ldy receives the rank's rows.
+static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_t ldx, void *Y_local, int64_t ldy, int mu, hipStream_t st) {
+    const HMatrix &H = d->hmat->H;
+    const size_t es = H.is_complex ? 16 : 8;
+    const int P = d->comm.size, rank = d->comm.rank;
+    HM_CHECK(mu >= 1, "mu must be >= 1");
+    HM_CHECK(H.dev != nullptr, "H-matrix has no device data");
+    if (!st) st = H.dev->stream; // the exchange and the product have to share one stream
+    if (P == 1 && !d->comm.rccl) { // one rank owns everything and there is no RCCL handle: the slice is the whole vector
+        device_matmat_device(H, X_local, (long long)ldx, Y_local, (long long)ldy, mu, 1, st);
+        return;
+    }
+    RcclComm *rc = static_cast<RcclComm *>(d->comm.rccl);
+    HM_CHECK(rc != nullptr && rc->comm != nullptr, "distributed device product: the communicator carries no RCCL handle (htool_comm_init_rccl / htool_comm_wrap_rccl)");
+    DistDeviceState *s = dist_state(d, mu);
+    HIP_OK(hipSetDevice(s->device));
+    const int mine = (int)d->s_counts[rank];
+    const size_t ns = (size_t)d->sc->n_points;
+    if (s->equal && mu == 1) {
+        // equal slices: gather straight from the caller's buffer into the contiguous vector (displs[p] = p * pad)
+        RCCL_OK(ncclAllGather(X_local, s->x_full, (size_t)s->pad * es, ncclUint8, rc->comm, st));
+    } else {
+        HIP_OK(hipMemcpy2DAsync(s->send, (size_t)s->pad * es, X_local, (size_t)ldx * es, (size_t)mine * es, (size_t)mu, hipMemcpyDeviceToDevice, st));
+        RCCL_OK(ncclAllGather(s->send, s->recv, (size_t)s->pad * mu * es, ncclUint8, rc->comm, st));
+        const dim3 grid((unsigned)((s->pad + 255) / 256), (unsigned)P, (unsigned)mu), block(256);
+        if (H.is_complex) hipLaunchKernelGGL(compact_slices_kernel<double2>, grid, block, 0, st, (const double2 *)s->recv, (double2 *)s->x_full, s->counts, s->displs, s->pad, mu, (long long)ns);
+        else hipLaunchKernelGGL(compact_slices_kernel<double>, grid, block, 0, st, (const double *)s->recv, (double *)s->x_full, s->counts, s->displs, s->pad, mu, (long long)ns);
+        HIP_OK(hipGetLastError());
+    }
+    device_matmat_device(H, s->x_full, (long long)ns, Y_local, (long long)ldy, mu, 1, st);
+}
+
+extern "C" {
+
+int htool_rccl_get_unique_id(void *id128) {
+    API_BEGIN
+    static_assert(sizeof(ncclUniqueId) == HTOOL_RCCL_UNIQUE_ID_BYTES, "unique id size");
+    HM_CHECK(id128 != nullptr, "htool_rccl_get_unique_id: null argument");
+    ncclUniqueId id;
+    RCCL_OK(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    API_END
+}
+
+int htool_comm_init_rccl(const void *id128, int rank, int size, htool_comm *out) {
+    API_BEGIN
+    HM_CHECK(id128 && out && size >= 1 && rank >= 0 && rank < size, "htool_comm_init_rccl: bad argument");
+    std::unique_ptr<RcclComm> c(new RcclComm);
+    HIP_OK(hipGetDevice(&c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    RCCL_OK(ncclCommInitRank(&c->comm, size, id, rank));
+    c->rank = rank;
+    c->size = size;
+    out->rank = rank;
+    out->size = size;
+    out->allgatherv = &rccl_host_allgatherv;
+    out->rccl = c.get();
+    out->ctx = c.release();
+    API_END
+}
+
+int htool_comm_wrap_rccl(void *nccl_comm, int rank, int size, htool_comm *out) {
+    API_BEGIN
+    HM_CHECK(nccl_comm && out && size >= 1 && rank >= 0 && rank < size, "htool_comm_wrap_rccl: bad argument");
+    std::unique_ptr<RcclComm> c(new RcclComm);
+    HIP_OK(hipGetDevice(&c->device));
+    c->comm = (ncclComm_t)nccl_comm;
+    c->owned = false;
+    c->rank = rank;
+    c->size = size;
+    out->rank = rank;
+    out->size = size;
+    out->allgatherv = &rccl_host_allgatherv;
+    out->rccl = c.get();
+    out->ctx = c.release();
+    API_END
+}
+
+void htool_comm_destroy_rccl(htool_comm *c) {
+    if (c && c->rccl) {
+        delete static_cast<RcclComm *>(c->rccl);
+        c->rccl = c->ctx = nullptr;
+        c->allgatherv = nullptr;
+    }
+}
+
+int htool_distributed_matvec_device(htool_distributed *d, const void *x_local_dev, void *y_local_dev, void *stream) {
+    API_BEGIN
+    dist_matmat_device(d, x_local_dev, 0, y_local_dev, 0, 1, (hipStream_t)stream);
+    API_END
+}
+
+int htool_distributed_matmat_device(htool_distributed *d, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream) {
+    API_BEGIN
+    dist_matmat_device(d, X_local_dev, ldx, Y_local_dev, ldy, mu, (hipStream_t)stream);
+    API_END
+}
+
+} // extern "C"

@@ -9,6 +9,7 @@
 #include <pybind11/stl.h>
 
 #include <complex>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <optional>
@@ -313,6 +314,24 @@ struct PyHMatrixTreeBuilder {
     }
 };
 
+// ---- RCCL communicator owned by the library (include/htool_mi355x.h: htool_comm_init_rccl) --------------------------
+struct PyRcclCommunicator {
+    htool_comm c;
+    PyRcclCommunicator(py::bytes id, int rank, int size) {
+        std::memset(&c, 0, sizeof(c));
+        std::string raw = id;
+        if (raw.size() != HTOOL_RCCL_UNIQUE_ID_BYTES) throw std::runtime_error("RcclCommunicator: the unique id must be the 128 bytes returned by Htool.rccl_unique_id() on one rank");
+        int rc;
+        {
+            py::gil_scoped_release nogil; // collective: blocks until every rank has arrived
+            rc = htool_comm_init_rccl(raw.data(), rank, size, &c);
+        }
+        check(rc);
+    }
+    PyRcclCommunicator(const PyRcclCommunicator &) = delete;
+    ~PyRcclCommunicator() { htool_comm_destroy_rccl(&c); }
+};
+
 // ---- communicator adapter (stand-in for the mpi4py caster of src/htool/misc/wrapper_mpi.hpp:28-55) ----
 struct PyComm {
     py::object obj;
@@ -333,8 +352,18 @@ struct PyComm {
         return 0;
     }
     explicit PyComm(py::object o) : obj(o) {
+        std::memset(&c, 0, sizeof(c));
         c.rank = py::cast<int>(o.attr("Get_rank")());
         c.size = py::cast<int>(o.attr("Get_size")());
+        // a communicator that carries a library-owned RCCL handle (Htool.RcclCommunicator, or the mpi4py stand-in after
+        // use_rccl()): the exchange then runs inside the library, on device buffers
+        py::object handle = py::hasattr(o, "_htool_comm_ptr") ? py::object(o.attr("_htool_comm_ptr")) : py::none();
+        if (!handle.is_none()) {
+            const htool_comm *lib = reinterpret_cast<const htool_comm *>(py::cast<std::uintptr_t>(handle));
+            if (lib->rank != c.rank || lib->size != c.size) throw std::runtime_error("communicator object and its RCCL handle disagree on rank / size");
+            c = *lib;
+            return;
+        }
         c.ctx = this;
         c.allgatherv = &allgatherv;
         if (c.size > 1 && !py::hasattr(o, "_htool_allgatherv")) throw std::runtime_error("communicator object must provide _htool_allgatherv (use the mpi4py shim shipped with this package)");
@@ -376,8 +405,12 @@ struct PyDefaultApproximationBuilder {
     PyCluster target, source;
     PyDistributedOperator<T> op;
     PyHMatrix<T> hmat, bdiag;
-    PyDefaultApproximationBuilder(PyIGenerator<T> &generator, const PyCluster &t, const PyCluster &s, const PyHMatrixTreeBuilder<T> &builder, py::object comm_obj)
-        : comm(std::make_shared<PyComm>(comm_obj)), target(t), source(s) {
+    py::object generator_ref, builder_ref; // the block-diagonal part is built on first use: keep what that build calls alive
+    bool bdiag_asked = false;
+    PyDefaultApproximationBuilder(py::object generator_obj, const PyCluster &t, const PyCluster &s, py::object builder_obj, py::object comm_obj)
+        : comm(std::make_shared<PyComm>(comm_obj)), target(t), source(s), generator_ref(generator_obj), builder_ref(builder_obj) {
+        PyIGenerator<T> &generator = generator_obj.cast<PyIGenerator<T> &>();
+        const PyHMatrixTreeBuilder<T> &builder = builder_obj.cast<const PyHMatrixTreeBuilder<T> &>();
         htool_build_params q = builder.resolved();
         check(htool_distributed_create_default(generator.get(), t.owner->root, s.owner->root, &q, &comm->c, &d));
         op.d = d;
@@ -387,10 +420,16 @@ struct PyDefaultApproximationBuilder {
         hmat.owned = false;
         hmat.target = t;
         hmat.source = s;
-        bdiag.h = htool_distributed_block_diagonal_hmatrix(d);
         bdiag.owned = false;
         bdiag.target = t;
         bdiag.source = s;
+    }
+    PyHMatrix<T> *block_diagonal() {
+        if (!bdiag_asked) {
+            bdiag_asked = true;
+            bdiag.h = htool_distributed_block_diagonal_hmatrix(d);
+        }
+        return bdiag.h ? &bdiag : nullptr;
     }
     ~PyDefaultApproximationBuilder() { htool_distributed_destroy(d); }
 };
@@ -606,6 +645,15 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("__matmul__", &Op::matmul, py::arg("input").noconvert(true))
         // extensions used by the GPU-resident Krylov loop (htool_python_amd/solver.py)
         .def_property_readonly("local_hmatrix", [](Op &o) { return o.local; }, py::return_value_policy::reference_internal)
+        // GPU-resident product: this rank's slice of x in, this rank's rows of y out (device pointers, cluster numbering);
+        // the exchange is an RCCL all-gather inside the library (htool_distributed_matvec_device)
+        .def("matvec_device", [](Op &o, std::uintptr_t x_local, std::uintptr_t y_local, std::uintptr_t stream) {
+                check(htool_distributed_matvec_device(o.d, (const void *)x_local, (void *)y_local, (void *)stream));
+            }, "x_local_ptr"_a, "y_local_ptr"_a, "stream"_a = 0)
+        .def("matmat_device", [](Op &o, std::uintptr_t x_local, long long ldx, std::uintptr_t y_local, long long ldy, int mu, std::uintptr_t stream) {
+                check(htool_distributed_matmat_device(o.d, (const void *)x_local, ldx, (void *)y_local, ldy, mu, (void *)stream));
+            }, "x_local_ptr"_a, "ldx"_a, "y_local_ptr"_a, "ldy"_a, "mu"_a, "stream"_a = 0)
+        .def_property_readonly("has_rccl", [](Op &o) { return o.comm->c.rccl != nullptr; })
         .def_property_readonly("comm", [](Op &o) { return o.comm->obj; })
         .def("partition", [](Op &o) {
                 std::vector<std::pair<int, int>> out;
@@ -618,10 +666,10 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
             });
     typedef PyDefaultApproximationBuilder<T> DA;
     py::class_<DA>(m, (prefix + "DefaultApproximationBuilder").c_str())
-        .def(py::init<PyIGenerator<T> &, const PyCluster &, const PyCluster &, const B &, py::object>())
+        .def(py::init<py::object, const PyCluster &, const PyCluster &, py::object, py::object>())
         .def_property_readonly("distributed_operator", [](DA &s) { return &s.op; }, py::return_value_policy::reference_internal)
         .def_property_readonly("hmatrix", [](DA &s) { return &s.hmat; }, py::return_value_policy::reference_internal)
-        .def_property_readonly("block_diagonal_hmatrix", [](DA &s) -> PyHMatrix<T> * { return s.bdiag.h ? &s.bdiag : nullptr; }, py::return_value_policy::reference_internal);
+        .def_property_readonly("block_diagonal_hmatrix", [](DA &s) -> PyHMatrix<T> * { return s.block_diagonal(); }, py::return_value_policy::reference_internal);
 }
 
 PYBIND11_MODULE(Htool, m) {
@@ -632,6 +680,18 @@ PYBIND11_MODULE(Htool, m) {
     m.def("device_name", []() { return std::string(htool_device_name()); });
     m.def("set_device", [](int d) { check(htool_set_device(d)); });
     m.def("set_num_threads", &htool_set_num_threads);
+    m.def("rccl_unique_id", []() {
+        char id[HTOOL_RCCL_UNIQUE_ID_BYTES];
+        check(htool_rccl_get_unique_id(id));
+        return py::bytes(id, sizeof(id));
+    }, "128-byte id for RcclCommunicator: call on ONE rank and broadcast the bytes to the others");
+    py::class_<PyRcclCommunicator>(m, "RcclCommunicator", "RCCL communicator owned by the library (one process per GPU); accepted wherever the reference takes mpi4py.MPI.COMM_WORLD")
+        .def(py::init<py::bytes, int, int>(), "unique_id"_a, "rank"_a, "size"_a)
+        .def("Get_rank", [](const PyRcclCommunicator &s) { return s.c.rank; })
+        .def("Get_size", [](const PyRcclCommunicator &s) { return s.c.size; })
+        .def_property_readonly("rank", [](const PyRcclCommunicator &s) { return s.c.rank; })
+        .def_property_readonly("size", [](const PyRcclCommunicator &s) { return s.c.size; })
+        .def_property_readonly("_htool_comm_ptr", [](const PyRcclCommunicator &s) { return (std::uintptr_t)&s.c; });
 
     py::class_<PyCluster>(m, "Cluster")
         .def("get_size", [](const PyCluster &c) { return htool_cluster_size(c.node); })

@@ -170,6 +170,24 @@ class DistributedOperator:
     def partition(self):
         return list(self._parts)
 
+    @property
+    def has_rccl(self):
+        """True when the communicator carries a library-owned RCCL handle: matvec_device / matmat_device then exchange
+        the vector slices inside the library (htool_distributed_matvec_device)."""
+        return self._core is not None and self._core.has_rccl
+
+    def matvec_device(self, x_local_ptr, y_local_ptr, stream=0):
+        """GPU-resident product of the default operator: this rank's slice of x in, its rows of y out (device pointers,
+        cluster numbering); the all-gather of the slices is RCCL inside the library."""
+        if not self.has_only_default_operator():
+            raise RuntimeError("matvec_device: only the default H-matrix operator has a device-resident product")
+        self._core.matvec_device(x_local_ptr, y_local_ptr, stream)
+
+    def matmat_device(self, x_local_ptr, ldx, y_local_ptr, ldy, mu, stream=0):
+        if not self.has_only_default_operator():
+            raise RuntimeError("matmat_device: only the default H-matrix operator has a device-resident product")
+        self._core.matmat_device(x_local_ptr, ldx, y_local_ptr, ldy, mu, stream)
+
     def has_only_default_operator(self):
         return self._core is not None and not self._g2l and not self._l2l
 

@@ -5,7 +5,8 @@ is a handful of library GEMV/AXPY calls on torch tensors (rocBLAS) -- plumbing, 
 Distributed runs keep one slice of every Krylov vector per GPU; the Gram-Schmidt coefficients of an
 iteration are reduced with ONE all-reduce per orthogonalisation pass (classical Gram-Schmidt applied
 twice, CGS2); the operator itself needs one all-gather of the iterate's slices.
-The (restart+1) x restart Hessenberg least-squares problem is solved on the host with numpy.
+The (restart+1) x restart Hessenberg least-squares problem is kept triangular on the host by Givens rotations (O(k) work per
+iteration on the k + 1 coefficients that come back from the device with the one synchronisation an iteration needs anyway).
 """
 import math
 
@@ -48,8 +49,13 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
             info["converged"] = True
             break
         V[0] = r / beta
-        Hh = np.zeros((m + 1, m), dtype=npdt)
-        y, k = None, 0
+        # Hessenberg matrix reduced to upper triangular form R by Givens rotations as its columns arrive; g = rotated beta e_1,
+        # |g[k]| = residual norm after k iterations
+        R = np.zeros((m + 1, m), dtype=npdt)
+        cs, sn = np.zeros(m, dtype=npdt), np.zeros(m, dtype=npdt)
+        g = np.zeros(m + 1, dtype=npdt)
+        g[0] = beta
+        k = 0
         for j in range(m):
             w = apply(V[j] if precond is None else precond(V[j]))
             Vj = V[: j + 1]
@@ -58,21 +64,40 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
             h2 = allsum(torch.mv(Vj.conj(), w))
             w = w - torch.mv(Vj.t(), h2)
             hn = norm(w)
-            Hh[: j + 1, j] = (h + h2).cpu().numpy()
-            Hh[j + 1, j] = hn
+            col = np.zeros(j + 2, dtype=npdt)
+            col[: j + 1] = (h + h2).cpu().numpy()
+            col[j + 1] = hn
             if hn > 0:
                 V[j + 1] = w / hn
+            for i in range(j):  # earlier rotations
+                t = cs[i] * col[i] + sn[i] * col[i + 1]
+                col[i + 1] = -np.conj(sn[i]) * col[i] + cs[i] * col[i + 1]
+                col[i] = t
+            a, b = col[j], col[j + 1]
+            denom = math.sqrt(abs(a) ** 2 + abs(b) ** 2)
+            if denom == 0.0:
+                cs[j], sn[j] = 1.0, 0.0
+            elif a == 0:
+                cs[j], sn[j] = 0.0, 1.0
+            else:  # c real, s complex: [c s; -conj(s) c] [a; b] = [r; 0]
+                cs[j] = abs(a) / denom
+                sn[j] = (a / abs(a)) * np.conj(b) / denom
+            col[j] = cs[j] * a + sn[j] * b
+            col[j + 1] = 0.0
+            R[: j + 2, j] = col
+            g[j + 1] = -np.conj(sn[j]) * g[j]
+            g[j] = cs[j] * g[j]
             k = j + 1
-            rhs = np.zeros(k + 1, dtype=npdt)
-            rhs[0] = beta
-            y = np.linalg.lstsq(Hh[: k + 1, :k], rhs, rcond=None)[0]
-            res = float(np.linalg.norm(rhs - Hh[: k + 1, :k] @ y)) / bnorm
+            res = abs(g[k]) / bnorm
             info["iterations"] += 1
-            info["residuals"].append(res)
+            info["residuals"].append(float(res))
             if callback is not None:
-                callback(info["iterations"], res)
+                callback(info["iterations"], float(res))
             if res <= tol or info["iterations"] >= max_it or hn == 0:
                 break
+        y = np.zeros(k, dtype=npdt)
+        for i in range(k - 1, -1, -1):  # back substitution R y = g
+            y[i] = (g[i] - R[i, i + 1: k] @ y[i + 1: k]) / R[i, i] if R[i, i] != 0 else 0.0
         dx = torch.mv(V[:k].t(), torch.from_numpy(y).to(device=dev, dtype=dt))
         x = x + (dx if precond is None else precond(dx))
         info["restarts"] += 1

@@ -41,7 +41,10 @@ def _parse_hpddm(args, opts):
 class DeviceOperator:
     """y_local = (shift I + A) x on GPU-resident slices in cluster numbering; A = this rank's rows."""
 
-    def __init__(self, hmatrix, partition=None, rank=0, group=None, shift=0.0):
+    def __init__(self, hmatrix, partition=None, rank=0, group=None, shift=0.0, dist_op=None):
+        # dist_op: the DistributedOperator this H-matrix belongs to; when its communicator carries a library-owned RCCL
+        # handle the exchange + product of apply() is ONE library call (htool_distributed_matvec_device)
+        self.dist_op = dist_op if (dist_op is not None and getattr(dist_op, "has_rccl", False)) else None
         self.H = hmatrix
         self.n = hmatrix.shape[1]
         self.partition = partition or [(0, self.n)]
@@ -54,6 +57,12 @@ class DeviceOperator:
     def apply(self, x_local):
         y = torch.empty(self.size, dtype=x_local.dtype, device=x_local.device)
         stream = torch.cuda.current_stream().cuda_stream
+        if self.dist_op is not None:
+            self.dist_op.matvec_device(x_local.contiguous().data_ptr(), y.data_ptr(), stream)
+            self.products += 1
+            if self.shift != 0.0:
+                y += self.shift * x_local
+            return y
         if self.world == 1:
             xf = x_local.contiguous()
         else:
@@ -119,6 +128,11 @@ class Solver:
         self._info = {}
         self._precond = None
         if distributed_operator is not None:
+            # the Krylov operator is the default H-matrix part only: an operator with extra user terms (add_global_to_local_operator /
+            # add_local_to_local_operator, tests/conftest.py "ExtraDiagonal") or without an H-matrix core would be solved wrongly
+            if not distributed_operator.has_only_default_operator():
+                raise RuntimeError("Solver: only a DistributedOperator made of its default H-matrix part (DefaultApproximationBuilder, no extra "
+                                   "global-to-local / local-to-local operators) can be solved on the HIP path")
             H = distributed_operator.local_hmatrix
             comm = distributed_operator.comm
             part = distributed_operator.partition()
@@ -126,7 +140,7 @@ class Solver:
             group = None
             if len(part) > 1:
                 comm._dist()  # make sure the process group exists
-            self.op = DeviceOperator(H, part, rank, group, shift)
+            self.op = DeviceOperator(H, part, rank, group, shift, dist_op=distributed_operator)
         else:
             self.op = DeviceOperator(hmatrix, None, 0, None, shift)
         assert self.op.H.shape[1] == sum(s for _, s in self.op.partition), "GMRES needs a square operator"

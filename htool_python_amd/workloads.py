@@ -40,19 +40,29 @@ def usable_cpus():
     return max(1, n)
 
 
-def gmres_shift(apply, n, dtype, fraction=None, power_its=6, seed=3):
+def gmres_shift(apply, n, dtype, fraction=None, power_its=6, seed=3, reduce=None):
     """Diagonal shift of the GMRES workloads (BASELINE config 5): a fixed fraction of the operator norm, estimated with a
     few power iterations of `apply` (device tensors), so that the shifted system (shift I + A) is well posed but not
-    trivial -- the Krylov method needs its iterations.  Returns (shift, norm estimate)."""
+    trivial -- the Krylov method needs its iterations.  `n` is this rank's slice length and `reduce(t)` sums a small device
+    tensor over the ranks (distributed runs).  Returns (shift, norm estimate)."""
+    import math
+
     import torch
+
+    def norm(t):
+        sq = torch.sum(t.real * t.real + t.imag * t.imag) if t.is_complex() else torch.sum(t * t)
+        sq = sq.reshape(1).to(torch.float64)
+        if reduce is not None:
+            reduce(sq)
+        return math.sqrt(float(sq[0]))
 
     g = torch.Generator(device="cpu").manual_seed(seed)
     v = torch.rand(n, dtype=torch.float64, generator=g).to(dtype).cuda()
     lam = 0.0
     for _ in range(power_its):
-        v = v / torch.linalg.norm(v)
+        v = v / norm(v)
         w = apply(v)
-        lam = float(torch.linalg.norm(w))
+        lam = norm(w)
         v = w
     return (GMRES_SHIFT_FRACTION if fraction is None else fraction) * lam, lam
 

@@ -228,13 +228,27 @@ double htool_hmatrix_last_product_us(const htool_hmatrix *h);
 int htool_hmatrix_phase_times(const htool_hmatrix *h, double *out4);
 
 /* ---- distributed operator (distributed_operator/utility.hpp:25-32, distributed_operator.hpp:18-65) */
-/* communicator supplied by the host language (mpi4py stand-in; backed by torch.distributed/RCCL or gloo).
- * allgatherv works on HOST buffers of bytes. */
+/* Communicator: rank / size plus (a) an RCCL communicator owned or wrapped by the library -- the opaque handle the
+ * GPU-resident exchange uses (one process per GPU, RCCL over xGMI; replaces the MPI_Comm the reference extracts from
+ * mpi4py, misc/wrapper_mpi.hpp:28-55) -- and / or (b) a host-buffer all-gather callback supplied by the host language
+ * (mpi4py stand-in over torch.distributed / gloo), which serves the replicated-vector API on boxes where several ranks
+ * share a GPU.  A communicator made by htool_comm_init_rccl / htool_comm_wrap_rccl has both: its allgatherv stages host
+ * buffers through device memory and RCCL. */
 typedef struct htool_comm {
     int rank, size;
     void *ctx;
     int (*allgatherv)(void *ctx, const void *send, int64_t send_bytes, void *recv, const int64_t *recv_bytes, const int64_t *displs);
+    void *rccl; /* opaque; NULL for a host-only communicator */
 } htool_comm;
+/* RCCL bootstrap (the NCCL pattern): ONE rank obtains a unique id, the host language broadcasts its 128 bytes to the
+ * other ranks by its own means, then every rank calls htool_comm_init_rccl on the device it selected with
+ * htool_set_device (collective: returns when all `size` ranks have called it). */
+#define HTOOL_RCCL_UNIQUE_ID_BYTES 128
+int htool_rccl_get_unique_id(void *id128);
+int htool_comm_init_rccl(const void *id128, int rank, int size, htool_comm *out);
+/* the same around a communicator the caller already has (ncclComm_t); it is not destroyed by htool_comm_destroy_rccl */
+int htool_comm_wrap_rccl(void *nccl_comm, int rank, int size, htool_comm *out);
+void htool_comm_destroy_rccl(htool_comm *comm);
 
 /* DefaultApproximationBuilder: builds rows(partition rank) x all columns */
 int htool_distributed_create_default(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
@@ -248,6 +262,14 @@ int htool_distributed_partition(const htool_distributed *d, int p, int *offset, 
 /* replicated user-numbered x in, replicated y out (distributed_operator.hpp:23-65) */
 int htool_distributed_matvec(const htool_distributed *d, const void *x, void *y);
 int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, void *Y);
+/* GPU-resident form of the same product (distributed_operator.hpp:33): every rank passes ITS slice of x (the positions of
+ * source partition `rank`, cluster numbering, device memory) and receives ITS rows of y (target partition `rank`, cluster
+ * numbering).  The library gathers the slices with ONE ncclAllGather (zero-copy for equal slices, padded slices plus one
+ * compaction kernel otherwise) and multiplies, all on `stream` (hipStream_t; NULL: the operator's own stream) without any
+ * host synchronisation.  Needs a communicator with an RCCL handle (or a single rank) and a source tree partitioned like
+ * the target tree.  The matmat form takes mu columns (column c at X_local + c * ldx elements) in one exchange. */
+int htool_distributed_matvec_device(htool_distributed *d, const void *x_local_dev, void *y_local_dev, void *stream);
+int htool_distributed_matmat_device(htool_distributed *d, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,24 @@ class _Comm:
             self._gloo = dist.new_group(backend="gloo")
         return self._gloo
 
+    # -- RCCL: the exchange of the GPU-resident product inside the library (one process per GPU)
+    def use_rccl(self):
+        """Create the library-owned RCCL communicator behind this communicator (collective over all ranks).  Afterwards a
+        DefaultApproximationBuilder built with it exchanges vector slices on device buffers (distributed_operator.matvec_device)
+        and serves the replicated-vector API through RCCL too.  Needs one GPU per rank (RCCL cannot share a device)."""
+        if getattr(self, "_rccl", None) is None:
+            import Htool
+
+            uid = Htool.rccl_unique_id() if self.rank == 0 else None
+            uid = self.bcast(uid, root=0)
+            self._rccl = Htool.RcclCommunicator(uid, self.rank, self.size)
+        return self
+
+    @property
+    def _htool_comm_ptr(self):
+        r = getattr(self, "_rccl", None)
+        return None if r is None else r._htool_comm_ptr
+
     def Barrier(self):
         if self.size > 1:
             self._dist().barrier(group=self._host_group())

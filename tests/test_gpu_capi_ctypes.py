@@ -73,3 +73,83 @@ def test_c_abi_end_to_end(built, oracle):
     L.htool_hmatrix_destroy(H)
     L.htool_generator_destroy(gen)
     L.htool_cluster_destroy(root)
+
+
+class HtoolComm(ctypes.Structure):
+    _fields_ = [("rank", ctypes.c_int), ("size", ctypes.c_int), ("ctx", ctypes.c_void_p), ("allgatherv", ctypes.c_void_p), ("rccl", ctypes.c_void_p)]
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_c_abi_distributed_device_product_with_rccl_communicator(built, oracle, monkeypatch, padded):
+    """The GPU-resident distributed product through the C ABI alone: RCCL bootstrap (unique id ->
+    htool_comm_init_rccl), DefaultApproximationBuilder's decomposition (htool_distributed_create_default), then
+    htool_distributed_matvec_device / _matmat_device on device buffers -- ncclAllGather of the x slices (zero-copy, or padded
+    slices + the compaction kernel) followed by the cluster-numbered local product.  One rank here (RCCL needs one GPU per
+    rank); the replicated-vector host API runs over the same communicator."""
+    O = oracle
+    monkeypatch.setenv("HTOOL_DIST_FORCE_PADDED", "1" if padded else "0")
+    L = ctypes.CDLL(built[0])
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    L.htool_last_error.restype = ctypes.c_char_p
+    L.htool_cluster_permutation.restype = ctypes.POINTER(ctypes.c_int)
+    L.htool_distributed_hmatrix.restype = ctypes.c_void_p
+    N = 6000
+    np.random.seed(1)
+    points = O.points_in_sphere(N)
+    pts = np.ascontiguousarray(points.T)
+    uid = ctypes.create_string_buffer(128)
+    assert L.htool_rccl_get_unique_id(uid) == 0, L.htool_last_error()
+    comm = HtoolComm()
+    assert L.htool_comm_init_rccl(uid, 0, 1, ctypes.byref(comm)) == 0, L.htool_last_error()
+    assert (comm.rank, comm.size) == (0, 1) and comm.rccl and comm.allgatherv
+    root, gen, dist = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.htool_cluster_create(pts.ctypes, N, 3, None, None, 2, 1, None, 0, 64, 0, ctypes.byref(root)) == 0
+    n = ctypes.c_int()
+    perm = np.ctypeslib.as_array(L.htool_cluster_permutation(root, ctypes.byref(n)), shape=(N,)).copy()
+    assert L.htool_generator_create_native(1, 3, pts.ctypes, N, pts.ctypes, N, ctypes.c_double(0.0), ctypes.byref(gen)) == 0
+    p = BuildParams()
+    L.htool_build_params_default(ctypes.byref(p))
+    p.epsilon, p.eta = 1e-5, 10.0
+    assert L.htool_distributed_create_default(gen, root, root, ctypes.byref(p), ctypes.byref(comm), ctypes.byref(dist)) == 0, L.htool_last_error()
+
+    def dev_buffer(nbytes):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes)) == 0
+        return ptr
+
+    mu = 3
+    X = np.random.rand(mu, N)                                  # row c = right-hand side c, USER numbering
+    Xc = np.ascontiguousarray(X[:, perm])                      # this rank's slices: cluster numbering (one rank: everything)
+    dX, dY = dev_buffer(Xc.nbytes), dev_buffer(Xc.nbytes)
+    assert hip.hipMemcpy(dX, Xc.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(Xc.nbytes), 1) == 0
+    Yc = np.zeros_like(Xc)
+    # single vector (stream NULL: the operator's own stream), then three columns in one exchange
+    assert L.htool_distributed_matvec_device(dist, dX, dY, None) == 0, L.htool_last_error()
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemcpy(Yc.ctypes.data_as(ctypes.c_void_p), dY, ctypes.c_size_t(N * 8), 2) == 0
+    y = np.zeros(N)
+    y[perm] = Yc[0]
+    ye = O.dense_matvec(O.K_LAPLACE, points, points, X[0])
+    assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < 1e-5
+    assert L.htool_distributed_matmat_device(dist, dX, ctypes.c_int64(N), dY, ctypes.c_int64(N), mu, None) == 0, L.htool_last_error()
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemcpy(Yc.ctypes.data_as(ctypes.c_void_p), dY, ctypes.c_size_t(Xc.nbytes), 2) == 0
+    assert np.array_equal(Yc[0][np.argsort(perm)], y)
+    for c in range(mu):
+        yc = np.zeros(N)
+        yc[perm] = Yc[c]
+        ye = O.dense_matvec(O.K_LAPLACE, points, points, X[c])
+        assert np.linalg.norm(yc - ye) / np.linalg.norm(ye) < 1e-5
+    # replicated-vector host API over the same communicator (distributed_operator.hpp:23-37)
+    yh = np.zeros(N)
+    assert L.htool_distributed_matvec(dist, X[0].ctypes, yh.ctypes) == 0, L.htool_last_error()
+    assert np.array_equal(yh, y)
+    rows, cols = ctypes.c_int(), ctypes.c_int()
+    L.htool_distributed_shape(dist, ctypes.byref(rows), ctypes.byref(cols))
+    assert (rows.value, cols.value) == (N, N)
+    hip.hipFree(dX)
+    hip.hipFree(dY)
+    L.htool_distributed_destroy(dist)
+    L.htool_comm_destroy_rccl(ctypes.byref(comm))
+    L.htool_generator_destroy(gen)
+    L.htool_cluster_destroy(root)
