@@ -158,7 +158,11 @@ static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_
         // equal slices: gather straight from the caller's buffer into the contiguous vector (displs[p] = p * pad)
         RCCL_OK(ncclAllGather(X_local, s->x_full, (size_t)s->pad * es, ncclUint8, rc->comm, st));
     } else {
-        HIP_OK(hipMemcpy2DAsync(s->send, (size_t)s->pad * es, X_local, (size_t)ldx * es, (size_t)mine * es, (size_t)mu, hipMemcpyDeviceToDevice, st));
+        if (mu == 1) HIP_OK(hipMemcpyAsync(s->send, X_local, (size_t)mine * es, hipMemcpyDeviceToDevice, st));
+        else {
+            HM_CHECK(ldx >= mine, "distributed device product: ldx is smaller than this rank's slice");
+            HIP_OK(hipMemcpy2DAsync(s->send, (size_t)s->pad * es, X_local, (size_t)ldx * es, (size_t)mine * es, (size_t)mu, hipMemcpyDeviceToDevice, st));
+        }
         RCCL_OK(ncclAllGather(s->send, s->recv, (size_t)s->pad * mu * es, ncclUint8, rc->comm, st));
         const dim3 grid((unsigned)((s->pad + 255) / 256), (unsigned)P, (unsigned)mu), block(256);
         if (H.is_complex) hipLaunchKernelGGL(compact_slices_kernel<double2>, grid, block, 0, st, (const double2 *)s->recv, (double2 *)s->x_full, s->counts, s->displs, s->pad, mu, (long long)ns);
