@@ -6,7 +6,7 @@ fallback: if the extension is missing the import fails.
 """
 from htool_python_amd.Htool import *  # noqa: F401,F403
 from htool_python_amd.Htool import __doc__ as _core_doc  # noqa: F401
-from htool_python_amd.io import load_hmatrix, save_hmatrix  # noqa: F401
+from htool_python_amd.io import load_hmatrix, read_cluster_from, save_cluster_to, save_hmatrix  # noqa: F401
 from htool_python_amd.plotting import plot  # noqa: F401
 from htool_python_amd.solver import DDMSolverBuilder, Solver  # noqa: F401,E402
 

@@ -121,22 +121,32 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
     build_block_tree(Tt, Ss, P, H.t_root, H.s_root, adm, dns);
     arena.clear();
     std::vector<T> U, V;
+    // borrowed factors (compress_borrows: the hook's U / V stay valid until the build returns): remembered here and copied
+    // ONCE, into their place in the arena, when the queue is done
+    struct Borrowed { size_t block; const T *u, *v; };
+    std::vector<Borrowed> borrowed;
     // low-rank queue; failures are re-split and appended to the queues
     for (size_t q = 0; q < adm.size(); q++) {
         BlockRec b = adm[q];
         const int *rows = &Tt.perm[b.t_off], *cols = &Ss.perm[b.s_off];
         int rank = -1;
+        bool lent = false;
         if (P.compress) {
             const void *pu = nullptr, *pv = nullptr;
             int r = 0;
             int ok = P.compress(P.compress_ctx, b.m, b.n, rows, cols, P.epsilon, &pu, &pv, &r);
             if (ok) {
                 rank = r;
-                U.assign((const T *)pu, (const T *)pu + (size_t)r * b.m);
-                V.resize((size_t)r * b.n);
-                const T *vv = (const T *)pv; // r x n column-major -> step-major [k][j]
-                for (int j = 0; j < b.n; j++)
-                    for (int k = 0; k < r; k++) V[(size_t)k * b.n + j] = vv[(size_t)j * r + k];
+                if (P.compress_borrows) {
+                    lent = true;
+                    borrowed.push_back({done.size(), (const T *)pu, (const T *)pv});
+                } else {
+                    U.assign((const T *)pu, (const T *)pu + (size_t)r * b.m);
+                    V.resize((size_t)r * b.n);
+                    const T *vv = (const T *)pv; // r x n column-major -> step-major [k][j]
+                    for (int j = 0; j < b.n; j++)
+                        for (int k = 0; k < r; k++) V[(size_t)k * b.n + j] = vv[(size_t)j * r + k];
+                }
             }
         } else {
             rank = host_aca<T>(g, b.m, b.n, rows, cols, P.epsilon, P.reqrank, b.t_off > b.s_off, U, V);
@@ -148,10 +158,19 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
         b.rank = rank;
         b.cap = rank;
         b.tmp_u = (int64_t)arena.size();
-        arena.insert(arena.end(), U.begin(), U.begin() + (size_t)rank * b.m);
+        if (lent) arena.resize(arena.size() + (size_t)rank * b.m); // (filled below)
+        else arena.insert(arena.end(), U.begin(), U.begin() + (size_t)rank * b.m);
         b.tmp_v = (int64_t)arena.size();
-        arena.insert(arena.end(), V.begin(), V.begin() + (size_t)rank * b.n);
+        if (lent) arena.resize(arena.size() + (size_t)rank * b.n);
+        else arena.insert(arena.end(), V.begin(), V.begin() + (size_t)rank * b.n);
         done.push_back(b);
+    }
+    for (const Borrowed &w : borrowed) {
+        const BlockRec &b = done[w.block];
+        std::copy(w.u, w.u + (size_t)b.rank * b.m, arena.begin() + b.tmp_u);
+        T *vd = &arena[0] + b.tmp_v; // r x n column-major -> step-major [k][j]
+        for (int j = 0; j < b.n; j++)
+            for (int k = 0; k < b.rank; k++) vd[(size_t)k * b.n + j] = w.v[(size_t)j * b.rank + k];
     }
     // dense queue
     size_t base = arena.size(), total = 0;

@@ -81,6 +81,14 @@ const htool_cluster *htool_cluster_on_partition(const htool_cluster *c, int p) {
     return reinterpret_cast<const htool_cluster *>(T->handle(T->part_nodes[p]));
 }
 int htool_cluster_dimension(const htool_cluster *c) { return CH(c)->tree->dim; }
+int htool_cluster_number_of_children(const htool_cluster *c) { return CH(c)->tree->n_children; }
+int htool_cluster_create_from_tables(int n_points, int dim, int maximal_leaf_size, int number_of_children, const int *permutation, int n_nodes,
+                                     const int *ints7, const double *doubles4, htool_cluster **out) {
+    API_BEGIN
+    ClusterTree *T = cluster_tree_from_tables(n_points, dim, maximal_leaf_size, number_of_children, permutation, n_nodes, ints7, doubles4);
+    *out = reinterpret_cast<htool_cluster *>(T->handle(0));
+    API_END
+}
 int htool_cluster_node_count(const htool_cluster *c) { return CH(c)->tree->node_count(); }
 int htool_cluster_node_id(const htool_cluster *c) { return CH(c)->node; }
 void htool_cluster_nodes(const htool_cluster *c, int *ints7, double *doubles4) {
@@ -187,6 +195,32 @@ static void fill_from_preset(HMatrix &H, const LeafPreset &ps) {
         }
         H.blocks.push_back(b);
     }
+    // The leaves have to tile the operator: no gaps, no overlaps (a truncated or mismatched file would otherwise give a wrong
+    // operator without any error).  Every leaf is a pair of cluster nodes (checked above), so its rows are a union of whole row
+    // tiles: for every row tile the column ranges of the leaves covering it must be disjoint and -- when both triangles are
+    // stored -- follow each other from the first to the last column.  One-triangle storage: disjointness per row tile, plus
+    // the total area with every off-diagonal leaf counted twice.
+    struct Piece { int tile, s_off, n; };
+    std::vector<Piece> pieces;
+    long double area = 0;
+    for (const BlockRec &b : H.blocks) {
+        for (int r = H.rtiles.node_tile_begin[b.t_node]; r < H.rtiles.node_tile_end[b.t_node]; r++) pieces.push_back({r, b.s_off, b.n});
+        area += (long double)b.m * b.n * ((H.one_triangle && b.t_off != b.s_off) ? 2 : 1);
+    }
+    std::sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.tile != y.tile ? x.tile < y.tile : x.s_off < y.s_off; });
+    const int col_end = H.col_off + H.col_size;
+    size_t i = 0;
+    for (int r = 0; r < H.rtiles.count(); r++) {
+        int pos = H.col_off;
+        for (; i < pieces.size() && pieces[i].tile == r; i++) {
+            HM_CHECK(pieces[i].s_off >= pos, strprintf("leaf table: two leaves overlap (row tile %d, column %d)", r, pieces[i].s_off));
+            HM_CHECK(H.one_triangle || pieces[i].s_off == pos, strprintf("leaf table: columns [%d, %d) of row tile %d are not covered by any leaf", pos, pieces[i].s_off, r));
+            pos = pieces[i].s_off + pieces[i].n;
+        }
+        HM_CHECK(H.one_triangle || pos == col_end, strprintf("leaf table: columns [%d, %d) of row tile %d are not covered by any leaf", pos, col_end, r));
+    }
+    const long double want = (long double)H.row_size * H.col_size;
+    HM_CHECK(area == want, strprintf("the leaves cover %.0Lf entries but the operator has %.0Lf: a truncated or mismatched leaf table", area, want));
 }
 
 static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root,
@@ -213,13 +247,20 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     H.params.min_target_depth = params->minimal_target_depth;
     H.params.min_source_depth = params->minimal_source_depth;
     H.params.block_tree_consistency = params->block_tree_consistency;
+    if (!params->block_tree_consistency)
+        log_message(LOG_DEBUG, "set_block_tree_consistency(False): accepted for compatibility -- upstream the flag governs how the POINTER tree of blocks is "
+                               "kept refinable for H-LU; this engine stores the leaves as two flat queues (no parent / child links) and the leaves are the same either way");
     H.params.compress = params->compress;
     H.params.compress_ctx = params->compress_ctx;
+    H.params.compress_borrows = params->compress_borrows;
     H.params.dense_blocks = params->dense_blocks;
     H.params.dense_blocks_ctx = params->dense_blocks_ctx;
     if (params->store_one_triangle) {
         const bool eligible = (params->symmetry == 'S' || params->symmetry == 'H') && (params->uplo == 'L' || params->uplo == 'U') && same_tree(T, S) && target_partition < 0 && source_partition < 0;
         if (eligible) { H.params.store_one_triangle = 1; H.one_triangle = true; }
+        else if (preset && params->symmetry != 'N' && params->uplo != 'N')
+            throw Error("htool_hmatrix_build_from_leaves: the leaves were saved as ONE triangle of a symmetric operator, but this configuration (two cluster "
+                        "trees, or a partition) cannot use one-triangle storage -- the other triangle would be lost");
         else if (params->symmetry != 'N') log_message(LOG_DEBUG, "symmetric build restricted to a partition or on two cluster trees: both triangles of the requested rows are stored");
     }
     if (target_partition >= 0) {
@@ -263,8 +304,10 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
 }
 
 int htool_hmatrix_build(const htool_generator *g, const htool_cluster *target_root, const htool_cluster *source_root, const htool_build_params *params,
-                        int target_partition_number, int /*partition_number_for_symmetry*/, htool_hmatrix **out) {
+                        int target_partition_number, int partition_number_for_symmetry, htool_hmatrix **out) {
     API_BEGIN
+    if (partition_number_for_symmetry >= 0 && partition_number_for_symmetry != target_partition_number)
+        log_message(LOG_WARNING, "partition_number_for_symmetry differs from target_partition_number: ignored (a build restricted to a partition stores both triangles of its rows)");
     *out = build_hmatrix(g, target_root, source_root, params, target_partition_number);
     API_END
 }

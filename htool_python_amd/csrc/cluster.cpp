@@ -298,4 +298,47 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
     return Tp.release();
 }
 
+// A cluster tree from its node table and permutation (read_cluster_from, src/htool/clustering/utility.hpp:10): the
+// counterpart of htool_cluster_nodes / htool_cluster_permutation.  Everything a build relies on is validated.
+ClusterTree *cluster_tree_from_tables(int n_points, int dim, int max_leaf, int n_children, const int *perm, int n_nodes, const int *ints7, const double *doubles4) {
+    HM_CHECK(n_points > 0 && n_nodes > 0 && perm && ints7 && doubles4, "cluster tree tables: null or empty argument");
+    HM_CHECK(dim >= 1 && dim <= 3, "cluster tree: spatial dimension must be 1, 2 or 3");
+    std::unique_ptr<ClusterTree> Tp(new ClusterTree);
+    ClusterTree &T = *Tp;
+    T.n_points = n_points; T.dim = dim; T.max_leaf = max_leaf; T.n_children = n_children;
+    T.perm.assign(perm, perm + n_points);
+    std::vector<char> seen((size_t)n_points, 0);
+    for (int i = 0; i < n_points; i++) {
+        HM_CHECK(perm[i] >= 0 && perm[i] < n_points && !seen[perm[i]], "cluster tree tables: the permutation is not a permutation");
+        seen[perm[i]] = 1;
+    }
+    for (int i = 0; i < n_nodes; i++) {
+        const int *r = ints7 + 7 * i;
+        const double *d = doubles4 + 4 * i;
+        T.offset.push_back(r[0]); T.size.push_back(r[1]); T.depth.push_back(r[2]); T.parent.push_back(r[3]);
+        T.first_child.push_back(r[4]); T.n_child.push_back(r[5]); T.partition.push_back(r[6]);
+        T.cx.push_back(d[0]); T.cy.push_back(d[1]); T.cz.push_back(d[2]); T.radius.push_back(d[3]);
+    }
+    HM_CHECK(T.offset[0] == 0 && T.size[0] == n_points && T.parent[0] == -1, "cluster tree tables: node 0 is not the root of all points");
+    for (int i = 0; i < n_nodes; i++) {
+        HM_CHECK(T.size[i] > 0 && T.offset[i] >= 0 && T.offset[i] + T.size[i] <= n_points, "cluster tree tables: node range outside the points");
+        if (T.n_child[i] == 0) continue;
+        const int f = T.first_child[i], nc = T.n_child[i];
+        HM_CHECK(f > i && f + nc <= n_nodes, "cluster tree tables: children must follow their parent in the node table");
+        int pos = T.offset[i];
+        for (int c = f; c < f + nc; c++) {
+            HM_CHECK(T.parent[c] == i && T.depth[c] == T.depth[i] + 1 && T.offset[c] == pos, "cluster tree tables: children do not tile their parent");
+            pos += T.size[c];
+        }
+        HM_CHECK(pos == T.offset[i] + T.size[i], "cluster tree tables: children do not tile their parent");
+    }
+    // the partition: the depth-1 children when the root carries partition -1, the root itself otherwise
+    if (T.partition[0] >= 0 || T.n_child[0] == 0) { T.n_partition = 1; T.part_nodes.push_back(0); }
+    else {
+        T.n_partition = T.n_child[0];
+        for (int c = 0; c < T.n_child[0]; c++) T.part_nodes.push_back(T.first_child[0] + c);
+    }
+    return Tp.release();
+}
+
 } // namespace hm

@@ -44,5 +44,6 @@ struct ClusterBuildArgs {
 };
 
 ClusterTree *build_cluster_tree(const ClusterBuildArgs &a);
+ClusterTree *cluster_tree_from_tables(int n_points, int dim, int max_leaf, int n_children, const int *perm, int n_nodes, const int *ints7, const double *doubles4);
 
 } // namespace hm

@@ -291,6 +291,9 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
 void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
+    // products of one handle share its coefficient workspace (and may re-allocate it): callers on several host threads are
+    // serialised here (launches only; the kernels of two calls on ONE stream run in order anyway)
+    std::lock_guard<std::recursive_mutex> lock(D->mu);
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
     const int need = D->one_triangle ? (mu >= 4 ? 4 : mu >= 2 ? 2 : 1) : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
@@ -321,6 +324,7 @@ static int host_numbering(const HMatrix &H) {
 void device_matvec_host(const HMatrix &H, const void *x, void *y) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
+    std::lock_guard<std::recursive_mutex> lock(D->mu); // x_tmp / y_tmp and the stream are per handle: one host product at a time
     HIP_OK(hipSetDevice(D->device));
     const size_t es = D->esize;
     HIP_OK(hipMemcpyAsync(D->x_tmp, x, (size_t)D->n_source * es, hipMemcpyHostToDevice, D->stream));
@@ -336,6 +340,7 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
 void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
+    std::lock_guard<std::recursive_mutex> lock(D->mu);
     HIP_OK(hipSetDevice(D->device));
     const size_t es = D->esize;
     const bool whole = H.t_root == 0;
@@ -419,55 +424,59 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     const DeviceHMatrix *S = src.dev;
     HM_CHECK(S != nullptr, "H-matrix has no device data");
     HIP_OK(hipSetDevice(S->device));
-    // Re-pack is not possible (the arena is gone), so copy buffers and relocate pointers in the tables.
-    DeviceHMatrix *D = new DeviceHMatrix(*S);
-    dst.dev = D;
-    D->stream = nullptr;
-    D->nprod = 0;
-    D->W16 = D->red16 = nullptr; // (created again by the copy's first 16-wide product)
-    D->n_red16 = 0;
+    // The copy starts EMPTY (no pointer of the source in it) and is owned by a guard until it is complete: when an
+    // allocation fails half-way -- out of memory is the realistic case for a multi-GB operator -- only buffers the copy
+    // itself allocated are freed, and the source stays intact.
+    struct Guard {
+        DeviceHMatrix *d;
+        ~Guard() { if (d) device_free(d); }
+    } guard{new DeviceHMatrix};
+    DeviceHMatrix *D = guard.d;
+    // scalar and host-side state
+    D->device = S->device; D->tabs = S->tabs; D->is_complex = S->is_complex; D->esize = S->esize;
+    D->nB = S->nB; D->nA = S->nA; D->nA2 = S->nA2; D->splitB = S->splitB; D->nB_split = S->nB_split;
+    D->one_triangle = S->one_triangle; D->conj_transposed = S->conj_transposed; D->nAT = S->nAT; D->nZ = S->nZ; D->n_zd_tiles = S->n_zd_tiles;
+    D->ycl_stride = S->ycl_stride; D->ypart_stride = S->ypart_stride; D->W_elems = S->W_elems; D->rhs_cap = S->rhs_cap;
+    for (int c = 0; c < 3; c++) { D->cntB[c] = S->cntB[c]; D->cntBs[c] = S->cntBs[c]; }
+    D->n_source = S->n_source; D->n_target = S->n_target; D->row_off = S->row_off; D->row_size = S->row_size; D->table_bytes = S->table_bytes;
+    D->batches.resize(S->batches.size());
+    for (size_t b = 0; b < S->batches.size(); b++) D->batches[b].bytes = S->batches[b].bytes;
     HIP_OK(hipStreamCreate(&D->stream));
-    for (auto &slot : D->pev) for (auto &e : slot) { e = nullptr; HIP_OK(hipEventCreate(&e)); }
-    auto dup = [](const void *p, size_t bytes) -> void * {
-        void *q = nullptr;
-        HIP_OK(dev_malloc(&q, std::max<size_t>(bytes, 1)));
-        if (p && bytes) HIP_OK(hipMemcpy(q, p, bytes, hipMemcpyDeviceToDevice));
-        return q;
-    };
+    for (auto &slot : D->pev) for (auto &e : slot) HIP_OK(hipEventCreate(&e));
+    // Re-pack is not possible (the arena is gone), so copy buffers and relocate pointers in the tables.
     struct Range { const char *old_lo, *old_hi; char *neu; };
     std::vector<Range> map;
-    const size_t es = S->esize;
-    // sizes of per-batch buffers are recomputed from the stored byte count split: keep it simple by
-    // querying the allocation sizes through hipMemPtrGetInfo
-    auto dup_alloc = [&](const void *p) -> void * {
-        if (!p) return nullptr;
+    // every buffer is assigned to its owner in the copy the moment it exists, so the guard frees it on failure
+    auto dup_into = [&](void **slot, const void *p) {
+        if (!p) return;
         size_t sz = 0;
         HIP_OK(hipMemPtrGetInfo(const_cast<void *>(p), &sz));
-        void *q = dup(p, sz);
-        map.push_back({(const char *)p, (const char *)p + sz, (char *)q});
-        return q;
+        HIP_OK(dev_malloc(slot, std::max<size_t>(sz, 1)));
+        if (sz) HIP_OK(hipMemcpy(*slot, p, sz, hipMemcpyDeviceToDevice));
+        map.push_back({(const char *)p, (const char *)p + sz, (char *)*slot});
     };
     for (size_t b = 0; b < S->batches.size(); b++) {
-        D->batches[b].panelB = dup_alloc(S->batches[b].panelB);
-        D->batches[b].panelA = dup_alloc(S->batches[b].panelA);
-        D->batches[b].cidxB = (int *)dup_alloc(S->batches[b].cidxB);
-        D->batches[b].oidxA = (int *)dup_alloc(S->batches[b].oidxA);
-        D->batches[b].zidxB = (int *)dup_alloc(S->batches[b].zidxB);
-        D->batches[b].tidxA = (int *)dup_alloc(S->batches[b].tidxA);
+        dup_into(&D->batches[b].panelB, S->batches[b].panelB);
+        dup_into(&D->batches[b].panelA, S->batches[b].panelA);
+        dup_into((void **)&D->batches[b].cidxB, S->batches[b].cidxB);
+        dup_into((void **)&D->batches[b].oidxA, S->batches[b].oidxA);
+        dup_into((void **)&D->batches[b].zidxB, S->batches[b].zidxB);
+        dup_into((void **)&D->batches[b].tidxA, S->batches[b].tidxA);
     }
-    D->zd_ptr = (int *)dup_alloc(S->zd_ptr);
-    D->zd_woff = (long long *)dup_alloc(S->zd_woff);
-    D->zd_rows = (int *)dup_alloc(S->zd_rows);
-    D->ycl = dup_alloc(S->ycl);
-    D->W = dup_alloc(S->W);
-    D->perm_s = (int *)dup_alloc(S->perm_s);
-    D->perm_t = (int *)dup_alloc(S->perm_t);
-    D->iota = (int *)dup_alloc(S->iota);
-    D->ones_idx = (int *)dup_alloc(S->ones_idx);
-    D->x_tmp = dup_alloc(S->x_tmp);
-    D->y_tmp = dup_alloc(S->y_tmp);
-    D->tcoord = (double *)dup_alloc(S->tcoord);
-    D->scoord = (double *)dup_alloc(S->scoord);
+    dup_into((void **)&D->zd_ptr, S->zd_ptr);
+    dup_into((void **)&D->zd_woff, S->zd_woff);
+    dup_into((void **)&D->zd_rows, S->zd_rows);
+    dup_into(&D->ycl, S->ycl);
+    dup_into(&D->W, S->W);
+    dup_into((void **)&D->perm_s, S->perm_s);
+    dup_into((void **)&D->perm_t, S->perm_t);
+    dup_into((void **)&D->iota, S->iota);
+    dup_into((void **)&D->ones_idx, S->ones_idx);
+    dup_into(&D->x_tmp, S->x_tmp);
+    dup_into(&D->y_tmp, S->y_tmp);
+    dup_into((void **)&D->tcoord, S->tcoord);
+    dup_into((void **)&D->scoord, S->scoord);
+    dup_into(&D->ypart, S->ypart);
     auto reloc = [&](const void *p) -> const void * {
         if (!p) return nullptr;
         for (auto &r : map) if ((const char *)p >= r.old_lo && (const char *)p < r.old_hi) return r.neu + ((const char *)p - r.old_lo);
@@ -492,11 +501,12 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     fix_tiles(S->tilesB_split, S->nB_split, &D->tilesB_split);
     fix_tiles(S->tilesAT, S->nAT, &D->tilesAT);
     fix_tiles(S->tilesZ, S->nZ, &D->tilesZ);
-    if (S->ypart) D->ypart = dup_alloc(S->ypart);
     segs.resize((size_t)nseg_used);
     for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); s.zidx = (const int *)reloc(s.zidx); s.oidx = (const int *)reloc(s.oidx); }
     D->segs = upload(segs);
-    (void)es;
+    // (the 16-wide workspace of the matrix-core sweep is created again by the copy's first such product)
+    dst.dev = D;
+    guard.d = nullptr;
 }
 
 // panels of one leaf, copied back to the host (introspection / parity tests)

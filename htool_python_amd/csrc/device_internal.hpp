@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,7 @@ struct BatchTables {
 };
 
 struct DeviceHMatrix {
+    std::recursive_mutex mu; // serialises the products of this handle issued from several host threads (shared workspace)
     int device = 0;
     std::vector<BatchTables> tabs;
     bool is_complex = false;

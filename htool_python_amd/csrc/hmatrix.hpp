@@ -87,6 +87,7 @@ struct BuildParams {
     int store_one_triangle = 0; // 'S'/'H' on one cluster tree: keep the UPLO triangle only and apply stored leaves transposed too
     int (*compress)(void *, int, int, const int *, const int *, double, const void **, const void **, int *) = nullptr;
     void *compress_ctx = nullptr;
+    int compress_borrows = 0; // the hook's U / V stay valid until the build returns: copied once, at the end of the host phase
     void (*dense_blocks)(void *, int, const int *, const int *, const int *, const int *, void **) = nullptr;
     void *dense_blocks_ctx = nullptr;
 };

@@ -160,9 +160,9 @@ struct PyVirtualLowRankGenerator {
         auto &Vm = self->mats_V.back();
         if (Um.ndim() != 2 || Vm.ndim() != 2 || Um.shape(0) != M || Vm.shape(1) != N || Um.shape(1) != Vm.shape(0)) throw std::runtime_error("set_U/set_V: expected U (M x r) and V (r x N)");
         *rank = (int)Um.shape(1);
-        // the panels live in HBM afterwards, so the library always copies; with allow_copy the Python
-        // references are dropped right away (virtual_low_rank_generator.hpp:33-38), otherwise they stay
-        // until clear_data() as in the reference (:39-42)
+        // allow_copy (virtual_low_rank_generator.hpp:33-38): the factors are copied out and the Python references dropped
+        // right away; otherwise (:39-42) the library borrows the Python arrays, which stay alive until clear_data()
+        // (htool_build_params.compress_borrows: read once, when the panels are shipped to HBM)
         *U = Um.data();
         *V = Vm.data();
         if (self->allow_copy) {
@@ -292,11 +292,41 @@ struct PyHMatrixTreeBuilder {
     }
     htool_build_params resolved() const {
         htool_build_params q = p;
-        if (low_rank) { q.compress = &PyVirtualLowRankGenerator<T>::trampoline; q.compress_ctx = low_rank.get(); }
+        if (low_rank) {
+            q.compress = &PyVirtualLowRankGenerator<T>::trampoline;
+            q.compress_ctx = low_rank.get();
+            // allow_copy=False (virtual_low_rank_generator.hpp:39-42): the factors are borrowed from the Python arrays, which
+            // the generator keeps alive until clear_data(); the library reads them once, when it ships the panels to HBM
+            q.compress_borrows = low_rank->allow_copy ? 0 : 1;
+        }
         if (dense_blocks) { q.dense_blocks = &PyVirtualDenseBlocksGenerator<T>::trampoline; q.dense_blocks_ctx = dense_blocks.get(); }
         return q;
     }
+    // The reference builds on the Cluster object it is given.  Here builds take the ROOT of a tree plus a partition number; a
+    // sub-cluster that is one of the tree's partitions (cluster.get_cluster_on_partition(p)) is mapped to that number, any
+    // other sub-cluster is refused instead of silently building the whole-root operator.
+    static int partition_of(const PyCluster &c, const char *which) {
+        if (c.node == c.owner->root) return -1;
+        for (int p = 0;; p++) {
+            const htool_cluster *s = htool_cluster_on_partition(c.owner->root, p);
+            if (!s) break;
+            if (s == c.node) return p;
+        }
+        throw std::runtime_error(std::string("HMatrixTreeBuilder.build: the ") + which + " cluster is neither the root of its tree nor one of its partitions; pass the root "
+                                 "cluster and target_partition_number (or use build_local for a (partition x partition) block)");
+    }
     PyHMatrix<T> build(PyIGenerator<T> &generator, const PyCluster &target, const PyCluster &source, int target_partition_number, int partition_number_for_symmetry) const {
+        const int tp = partition_of(target, "target"), sp = partition_of(source, "source");
+        if (tp >= 0 && target_partition_number >= 0 && tp != target_partition_number) throw std::runtime_error("HMatrixTreeBuilder.build: target cluster and target_partition_number disagree");
+        if (tp >= 0) target_partition_number = tp;
+        if (sp >= 0) { // a source partition: the (target partition x source partition) block (as build_local)
+            PyHMatrix<T> Hl;
+            Hl.target = target;
+            Hl.source = source;
+            htool_build_params ql = resolved();
+            check(htool_hmatrix_build_local(generator.get(), target.owner->root, source.owner->root, &ql, target_partition_number, sp, &Hl.h));
+            return Hl;
+        }
         PyHMatrix<T> H;
         H.target = target;
         H.source = source;
@@ -591,16 +621,22 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
     };
     m.def("recompression", [recompress](H &s) { return recompress(s); });
     m.def("recompression", [recompress](H &s, double epsilon) { return recompress(s, epsilon); }, "hmatrix"_a, "epsilon"_a); // extension: explicit tolerance
-    m.def("recompression", [recompress](H &s, py::object) {
-        python_log_sink(2, "recompression(hmatrix, fn): user-defined recompression callables are not supported on the HIP path; using the built-in SVD rule");
-        return recompress(s);
-    });
+    // recompression(hmatrix, fn) (hmatrix.hpp:96): the reference hands every low-rank leaf to fn as a LowRankMatrix INSTEAD of
+    // applying its built-in rule; through the binding fn sees nb_rows / nb_cols / rank (lrmat.hpp:15-17) and nothing it could
+    // change, so the call is a visit of the low-rank leaves: reproduced as such (host callback per leaf, nothing recompressed).
+    auto visit_low_rank = [](H &s, py::function fn) {
+        const int64_t n = htool_hmatrix_leaf_count(s.h);
+        std::vector<int> all((size_t)n * 5);
+        htool_hmatrix_leaves(s.h, all.data());
+        int64_t visited = 0;
+        for (int64_t i = 0; i < n; i++)
+            if (all[5 * i + 4] >= 0) { fn(LowRank{all[5 * i + 1], all[5 * i + 3], all[5 * i + 4]}); visited++; }
+        return visited;
+    };
+    m.def("recompression", [visit_low_rank](H &s, py::function fn) { return visit_low_rank(s, fn); }, "hmatrix"_a, "recompression_function"_a);
     m.def("openmp_recompression", [recompress](H &s) { return recompress(s); });
     m.def("openmp_recompression", [recompress](H &s, double epsilon) { return recompress(s, epsilon); }, "hmatrix"_a, "epsilon"_a);
-    m.def("openmp_recompression", [recompress](H &s, py::object) {
-        python_log_sink(2, "openmp_recompression(hmatrix, fn): user-defined recompression callables are not supported on the HIP path; using the built-in SVD rule");
-        return recompress(s);
-    });
+    m.def("openmp_recompression", [visit_low_rank](H &s, py::function fn) { return visit_low_rank(s, fn); }, "hmatrix"_a, "recompression_function"_a);
 
     // HMatrixTreeBuilder (hmatrix/hmatrix_tree_builder.hpp:10-44)
     typedef PyHMatrixTreeBuilder<T> B;
@@ -715,7 +751,19 @@ PYBIND11_MODULE(Htool, m) {
                 htool_cluster_nodes(c.node, ints.mutable_data(), dbl.mutable_data());
                 return py::make_tuple(ints, dbl);
             })
-        .def("_node_id", [](const PyCluster &c) { return htool_cluster_node_id(c.node); });
+        .def("_node_id", [](const PyCluster &c) { return htool_cluster_node_id(c.node); })
+        .def("_dimension", [](const PyCluster &c) { return htool_cluster_dimension(c.node); })
+        .def("_number_of_children", [](const PyCluster &c) { return htool_cluster_number_of_children(c.node); });
+
+    m.def("_cluster_from_tables", [](int dim, int maximal_leaf_size, int number_of_children, py::array_t<int, py::array::c_style | py::array::forcecast> permutation,
+                                     py::array_t<int, py::array::c_style | py::array::forcecast> ints7, py::array_t<double, py::array::c_style | py::array::forcecast> doubles4) {
+        if (permutation.ndim() != 1 || ints7.ndim() != 2 || ints7.shape(1) != 7 || doubles4.ndim() != 2 || doubles4.shape(1) != 4 || doubles4.shape(0) != ints7.shape(0))
+            throw std::runtime_error("cluster tables: permutation (n), node ints (k, 7), node doubles (k, 4) expected");
+        auto owner = std::make_shared<ClusterRoot>();
+        check(htool_cluster_create_from_tables((int)permutation.shape(0), dim, maximal_leaf_size, number_of_children, permutation.data(), (int)ints7.shape(0), ints7.data(), doubles4.data(),
+                                               &owner->root));
+        return PyCluster{owner, owner->root};
+    }, "dim"_a, "maximal_leaf_size"_a, "number_of_children"_a, "permutation"_a, "node_ints"_a, "node_doubles"_a);
 
     py::class_<PyPartitioning, std::shared_ptr<PyPartitioning>>(m, "VirtualPartitioning");
     py::class_<PyPartitioningT<HTOOL_PCA_REGULAR>, std::shared_ptr<PyPartitioningT<HTOOL_PCA_REGULAR>>, PyPartitioning>(m, "PCARegular").def(py::init<>());

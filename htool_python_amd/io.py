@@ -27,7 +27,7 @@ def save_hmatrix(path, hmatrix):
              leaves=leaves, offsets=np.asarray(offsets, dtype=np.int64), data=np.asarray(data),
              epsilon=float(info["Epsilon"]), eta=float(info["Eta"]), symmetry=info["Symmetry"], uplo=info["UPLO"],
              one_triangle=bool(hmatrix.is_one_triangle()), is_complex=isinstance(hmatrix, Htool.ComplexHMatrix),
-             shape=np.asarray(hmatrix.shape, dtype=np.int64),
+             shape=np.asarray(hmatrix.shape, dtype=np.int64), n_leaves=len(leaves),
              target_offset=int(target.get_offset()), target_size=int(target.get_size()),
              target_permutation=np.asarray(target.get_permutation(), dtype=np.int32),
              source_permutation=np.asarray(source.get_permutation(), dtype=np.int32))
@@ -44,9 +44,58 @@ def load_hmatrix(path, target_cluster, source_cluster=None, target_partition_num
         same_s = np.array_equal(f["source_permutation"], np.asarray(source_cluster.get_permutation()))
         if not (same_t and same_s):
             raise RuntimeError("load_hmatrix: the cluster trees are not the ones the H-matrix was saved with (permutations differ)")
+        if "n_leaves" in f and int(f["n_leaves"]) != len(f["leaves"]):
+            raise RuntimeError("load_hmatrix: the file is truncated (leaf count does not match the leaf table)")
+        part = target_cluster if target_partition_number < 0 else target_cluster.get_cluster_on_partition(target_partition_number)
+        if (int(f["target_offset"]), int(f["target_size"])) != (part.get_offset(), part.get_size()):
+            raise RuntimeError(f"load_hmatrix: the operator was saved for rows [{int(f['target_offset'])}, +{int(f['target_size'])}) but target_partition_number="
+                               f"{target_partition_number} selects [{part.get_offset()}, +{part.get_size()})")
         make = _core._complex_hmatrix_from_leaves if bool(f["is_complex"]) else _core._hmatrix_from_leaves
         H = make(target_cluster, source_cluster, float(f["epsilon"]), float(f["eta"]), str(f["symmetry"]), str(f["uplo"]), bool(f["one_triangle"]),
                  int(target_partition_number), f["leaves"], f["offsets"], f["data"])
         if tuple(int(v) for v in f["shape"]) != tuple(H.shape):
             raise RuntimeError(f"load_hmatrix: saved shape {tuple(f['shape'])} but the clusters give {tuple(H.shape)} (wrong target_partition_number?)")
     return H
+
+
+# ----------------------------------------------------------------------------------------------
+# cluster trees on disk (read_cluster_from, src/htool/clustering/utility.hpp:10; used at tests/conftest.py:446-449)
+# ----------------------------------------------------------------------------------------------
+# The reference reads two CSV files written by lib/htool's save_cluster_tree ("<prefix>_cluster_tree_properties.csv" and
+# "<prefix>_cluster_tree.csv").  lib/htool and its data files are not in the container, so that format cannot be
+# reproduced verifiably; this pair of functions uses the package's own, documented layout (round trip tested):
+#   properties file:  "key: value" lines -- space_dimension, number_of_points, maximal_leaf_size, number_of_children,
+#                     number_of_nodes, and "permutation: i0,i1,..." (cluster position -> user index)
+#   tree file:        one line per node, parents before children:
+#                     offset,size,depth,parent,first_child,n_children,partition,cx,cy,cz,radius
+def save_cluster_to(cluster, properties_file, tree_file):
+    ints, dbl = cluster._nodes()
+    perm = np.asarray(cluster.get_permutation())
+    with open(properties_file, "w") as f:
+        f.write(f"space_dimension: {cluster._dimension()}\nnumber_of_points: {len(perm)}\nmaximal_leaf_size: {cluster.get_maximal_leaf_size()}\n")
+        f.write(f"number_of_children: {cluster._number_of_children()}\nnumber_of_nodes: {len(ints)}\n")
+        f.write("permutation: " + ",".join(str(int(v)) for v in perm) + "\n")
+    with open(tree_file, "w") as f:
+        for r, d in zip(np.asarray(ints), np.asarray(dbl)):
+            f.write(",".join(str(int(v)) for v in r) + "," + ",".join(repr(float(v)) for v in d) + "\n")
+
+
+def read_cluster_from(properties_file, tree_file):
+    """Htool.read_cluster_from(properties_csv, tree_csv) -> Cluster (root).  See save_cluster_to for the file layout."""
+    from . import Htool as _core
+
+    props = {}
+    with open(properties_file) as f:
+        for line in f:
+            if ":" in line:
+                key, val = line.split(":", 1)
+                props[key.strip()] = val.strip()
+    try:
+        perm = np.array([int(v) for v in props["permutation"].split(",")], dtype=np.int32)
+        dim, max_leaf, nch = int(props["space_dimension"]), int(props["maximal_leaf_size"]), int(props["number_of_children"])
+    except (KeyError, ValueError) as e:
+        raise RuntimeError(f"read_cluster_from: {properties_file} is not a cluster properties file of this package ({e})")
+    rows = np.loadtxt(tree_file, delimiter=",", ndmin=2)
+    if rows.shape[1] != 11 or len(perm) != int(props.get("number_of_points", -1)) or len(rows) != int(props.get("number_of_nodes", -1)):
+        raise RuntimeError("read_cluster_from: the tree file does not match the properties file")
+    return _core._cluster_from_tables(dim, max_leaf, nch, perm, rows[:, :7].astype(np.int32), np.ascontiguousarray(rows[:, 7:]))

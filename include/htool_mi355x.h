@@ -73,6 +73,12 @@ int htool_cluster_dimension(const htool_cluster *c);
 int htool_cluster_node_count(const htool_cluster *c);
 int htool_cluster_node_id(const htool_cluster *c);
 void htool_cluster_nodes(const htool_cluster *c, int *ints7, double *doubles4);
+int htool_cluster_number_of_children(const htool_cluster *c);
+/* the inverse of htool_cluster_permutation + htool_cluster_nodes: a cluster tree from its tables (read_cluster_from,
+ * clustering/utility.hpp:10 -- the reference reads the two CSV files lib/htool writes; the host language parses the files
+ * and hands the tables over).  The tables are validated (permutation, children tiling their parents). */
+int htool_cluster_create_from_tables(int n_points, int dim, int maximal_leaf_size, int number_of_children, const int *permutation, int n_nodes,
+                                     const int *ints7, const double *doubles4, htool_cluster **out);
 
 /* ---- generators (hmatrix/interfaces/virtual_generator.hpp:16-25) ----------------------------- */
 /* callback flavour: out is column-major M x N, rows/cols in user numbering.  Only ever invoked on
@@ -94,7 +100,8 @@ void htool_generator_destroy(htool_generator *g);
 /* ---- builder hooks ---------------------------------------------------------------------------- */
 /* custom compressor (hmatrix/interfaces/virtual_low_rank_generator.hpp:25-45): return 1 and set
  * U (M x rank, column-major), V (rank x N, column-major) on success, 0 when not worthwhile.
- * The library copies U and V before the next call. */
+ * The library copies U and V before the next call, or -- htool_build_params.compress_borrows = 1 -- borrows them until
+ * the build returns. */
 typedef int (*htool_compress_fn)(void *ctx, int M, int N, const int *rows, const int *cols, double epsilon,
                                  const void **U, const void **V, int *rank);
 /* batched dense fill (hmatrix/interfaces/virtual_dense_blocks_generator.hpp:21-35): block i is
@@ -116,6 +123,12 @@ typedef struct htool_build_params {
     void *compress_ctx;
     htool_dense_blocks_fn dense_blocks; /* NULL: generator */
     void *dense_blocks_ctx;
+    /* copy-or-borrow of the compress hook's factors (virtual_low_rank_generator.hpp:33-42, allow_copy).  0 (default): the
+     * library copies U and V before it calls the hook again (the hook may reuse its buffers).  1: the hook guarantees that
+     * every U / V it returned stays valid until htool_hmatrix_build returns; the library then reads them only once, when it
+     * ships the panels to HBM at the end of the host phase -- no intermediate host copy.  Either way nothing is referenced
+     * after the build: the panels live in device memory. */
+    int compress_borrows;
     /* 1 (default): a symmetric or Hermitian ('S' / 'H', UPLO 'L'/'U') operator built on one cluster tree without
      * partition restriction keeps the UPLO triangle only, like the reference, and the product applies
      * every stored off-diagonal leaf a second time, (conjugate) transposed, in the same pass over its panels.

@@ -150,6 +150,9 @@ def independent_leaf_checks(hmatrix, points_t, points_s, kind, p0, eps, n_sample
     cand = np.flatnonzero((L[:, 4] > 0) & (L[:, 1] <= max_block) & (L[:, 3] <= max_block))
     rng = np.random.RandomState(seed)
     pick = rng.choice(cand, min(n_sample, len(cand)), replace=False)
+    if len(pick) == 0:  # (tiny blocks at a tight tolerance: every admissible block was refused, r (m + n) > m n)
+        assert min_leaves == 0, "no low-rank leaf to check"
+        return None
     same = pm1 = 0
     errs, over_svd, e2, a2 = [], [], 0.0, 0.0
     for i in pick:

@@ -139,7 +139,7 @@ def test_rectangular_and_host_aca_ranks_match_oracle(built, oracle):
         y = H * x
         ye = gen.mat_vec(x)
         assert np.linalg.norm(y - ye) / np.linalg.norm(ye) < epsilon
-        independent_leaf_checks(H, T, S, O.K_INV_DELTA, 0.1, epsilon, n_sample=200, transpose_rule=True)
+        independent_leaf_checks(H, T, S, O.K_INV_DELTA, 0.1, epsilon, n_sample=200, transpose_rule=True, min_leaves=20 if epsilon == 1e-3 else 0)
         otc, osc = O.Cluster(T, max_leaf=10), O.Cluster(S, max_leaf=10)
         assert np.array_equal(otc.perm, np.asarray(tcl.get_permutation()))
         assert np.array_equal(osc.perm, np.asarray(scl.get_permutation()))

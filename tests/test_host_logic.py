@@ -324,3 +324,61 @@ def test_one_triangle_eligibility_of_separately_built_trees(built):
     a_other, d_other = Htool.block_tree_queues(t1, other, 10.0, symmetry="S", UPLO="L")
     a_plain, d_plain = Htool.block_tree_queues(t1, other, 10.0)
     assert np.array_equal(a_other, a_plain) and np.array_equal(d_other, d_plain)   # not eligible: every block is kept
+
+
+def test_read_cluster_from_round_trip(built, tmp_path):
+    """Htool.read_cluster_from (src/htool/clustering/utility.hpp:10; tests/conftest.py:446-449): a cluster tree written by
+    save_cluster_to and read back is the same tree -- permutation, node table, partitions -- and usable as such."""
+    import Htool
+
+    pts = np.random.RandomState(4).rand(3, 700)
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(15)
+    cl = b.create_cluster_tree(pts, 2, size_of_partition=3)
+    props, tree = str(tmp_path / "c_cluster_tree_properties.csv"), str(tmp_path / "c_cluster_tree.csv")
+    Htool.save_cluster_to(cl, props, tree)
+    back = Htool.read_cluster_from(props, tree)
+    assert np.array_equal(np.asarray(back.get_permutation()), np.asarray(cl.get_permutation()))
+    (i0, d0), (i1, d1) = cl._nodes(), back._nodes()
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    assert back.get_size() == 700 and back.get_maximal_leaf_size() == 15
+    for p in range(3):
+        a, c = cl.get_cluster_on_partition(p), back.get_cluster_on_partition(p)
+        assert (a.get_offset(), a.get_size()) == (c.get_offset(), c.get_size())
+    # same block tree on the tree that was read
+    q0, q1 = Htool.block_tree_queues(cl, cl, 10.0), Htool.block_tree_queues(back, back, 10.0)
+    assert np.array_equal(q0[0], q1[0]) and np.array_equal(q0[1], q1[1])
+    # damaged files are refused
+    lines = open(tree).read().splitlines()
+    open(tree, "w").write("\n".join(lines[:-3]) + "\n")
+    with pytest.raises(RuntimeError):
+        Htool.read_cluster_from(props, tree)
+    rows = [ln.split(",") for ln in lines]
+    rows[1][1] = str(int(rows[1][1]) + 1)  # a child that no longer tiles its parent
+    open(tree, "w").write("\n".join(",".join(r) for r in rows) + "\n")
+    with pytest.raises(RuntimeError, match="tile"):
+        Htool.read_cluster_from(props, tree)
+
+
+@pytest.mark.parametrize("min_t,min_s", [(0, 0), (4, 0), (0, 5), (6, 6)])
+def test_minimal_depths_of_the_block_tree(built, min_t, min_s):
+    """set_minimal_target_depth / set_minimal_source_depth (hmatrix_tree_builder.hpp:39-40): no block shallower than the
+    minimal depths is taken as admissible; the queues still tile the matrix."""
+    import Htool
+
+    pts = np.random.RandomState(6).rand(3, 900)
+    b = Htool.ClusterTreeBuilder()
+    cl = b.create_cluster_tree(pts, 2)
+    ints, _ = cl._nodes()
+    depth = {(r[0], r[1]): r[2] for r in ints}
+    adm, dns = Htool.block_tree_queues(cl, cl, 100.0, min_target_depth=min_t, min_source_depth=min_s)
+    assert len(adm) > 0
+    for t_off, m, s_off, n in np.asarray(adm):
+        assert depth[(t_off, m)] >= min_t and depth[(s_off, n)] >= min_s
+    a0, _ = Htool.block_tree_queues(cl, cl, 100.0)
+    if min_t or min_s:  # with eta = 100 the unconstrained tree has admissible blocks above these depths
+        assert min(min(depth[(t, m)], depth[(s, n)]) for t, m, s, n in np.asarray(a0)) < max(min_t, min_s)
+    cover = np.zeros((900, 900), dtype=np.int8)
+    for t_off, m, s_off, n in list(np.asarray(adm)) + list(np.asarray(dns)):
+        cover[t_off:t_off + m, s_off:s_off + n] += 1
+    assert cover.min() == 1 and cover.max() == 1
