@@ -180,14 +180,16 @@ def test_damaged_checkpoints_are_refused(built, oracle, tmp_path):
     np.savez(str(tmp_path / "trunc.npz"), **g)
     with pytest.raises(RuntimeError, match="truncated"):
         Htool.load_hmatrix(str(tmp_path / "trunc.npz"), cl)
-    # one triangle of a symmetric operator, loaded on two separately partitioned trees: refused
+    # one triangle of a symmetric operator, loaded where one-triangle storage is not possible: refused
     Hs = Htool.HMatrixTreeBuilder(1e-4, 10.0, "S", "L").build(gen, cl, cl)
     assert Hs.is_one_triangle()
     ps = str(tmp_path / "sym.npz")
     Htool.save_hmatrix(ps, Hs)
     assert np.array_equal(Htool.load_hmatrix(ps, cl) * x, Hs * x)
+    with pytest.raises(RuntimeError, match="ONE triangle"):
+        Htool.load_hmatrix(ps, cl, target_partition_number=0)  # (a build restricted to a partition cannot store one triangle)
     b2 = Htool.ClusterTreeBuilder()
     b2.set_maximal_leaf_size(16)
     other = b2.create_cluster_tree(pts[:, ::-1].copy(), 2)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="permutations differ"):
         Htool.load_hmatrix(ps, cl, other)
