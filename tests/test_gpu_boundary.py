@@ -164,7 +164,7 @@ def test_damaged_checkpoints_are_refused(built, oracle, tmp_path):
     path = str(tmp_path / "h.npz")
     Htool.save_hmatrix(path, H)
     x = np.random.rand(2000)
-    assert np.array_equal(Htool.load_hmatrix(path, cl) * x, H * x)
+    assert np.linalg.norm(Htool.load_hmatrix(path, cl) * x - H * x) <= 1e-12 * np.linalg.norm(H * x)  # (same panels, other column order)
     f = dict(np.load(path))
     for name, edit in (("missing", lambda L: L[:-1]), ("repeated", lambda L: np.vstack([L[:-1], L[:1]]))):
         g = dict(f)
@@ -185,7 +185,7 @@ def test_damaged_checkpoints_are_refused(built, oracle, tmp_path):
     assert Hs.is_one_triangle()
     ps = str(tmp_path / "sym.npz")
     Htool.save_hmatrix(ps, Hs)
-    assert np.array_equal(Htool.load_hmatrix(ps, cl) * x, Hs * x)
+    assert np.linalg.norm(Htool.load_hmatrix(ps, cl) * x - Hs * x) <= 1e-12 * np.linalg.norm(Hs * x)
     with pytest.raises(RuntimeError, match="ONE triangle"):
         Htool.load_hmatrix(ps, cl, target_partition_number=0)  # (a build restricted to a partition cannot store one triangle)
     b2 = Htool.ClusterTreeBuilder()
