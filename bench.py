@@ -204,6 +204,9 @@ def main():
     if args.backend == "gloo":  # rehearsal: ranks may share a GPU
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # every torch op and every product of this process goes to ONE explicit stream (not the legacy default stream): ordering is
+    # then plain stream order, and the library may replay the captured launches of a repeated product as a hipGraph
+    torch.cuda.set_stream(torch.cuda.Stream())
     import torch.distributed as dist
 
     dist_mode = world > 1 or args.force_dist

@@ -163,10 +163,17 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     if (timing) D->nprod++;
 }
 
+// forget the captured product (its kernel arguments point into tables / workspaces that are about to change)
+static void drop_product_graph(DeviceHMatrix *D) {
+    if (D->graph.exec) (void)hipGraphExecDestroy(D->graph.exec);
+    D->graph = ProductGraph();
+}
+
 // make room for nr coefficient workspaces (and partial-y slabs); W[r][n_source] = 1 for every r
 template <typename T>
 static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     if (nr <= D->rhs_cap) return;
+    drop_product_graph(D);
     void *nW = nullptr;
     HIP_OK(dev_malloc(&nW, (size_t)nr * D->W_elems * sizeof(T)));
     HIP_OK(hipMemset(nW, 0, (size_t)nr * D->W_elems * sizeof(T)));
@@ -211,6 +218,7 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
 // ---- sixteen right-hand sides per sweep on the matrix cores (real operators, both triangles stored) ----
 static void ensure_w16(DeviceHMatrix *D) {
     if (D->W16) return;
+    drop_product_graph(D);
     void *w = nullptr;
     HIP_OK(dev_malloc(&w, (size_t)D->W_elems * 16 * sizeof(double)));
     HIP_OK(hipMemset(w, 0, (size_t)D->W_elems * 16 * sizeof(double)));
@@ -306,8 +314,48 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
         if (D->is_complex) ensure_rhs_capacity<double2>(D, need);
         else ensure_rhs_capacity<double>(D, need);
     }
-    if (D->is_complex) launch_product<CplxOps>(D, X, x_stride, Y, y_stride, mu, numbering, st);
-    else launch_product<RealOps>(D, X, x_stride, Y, y_stride, mu, numbering, st);
+    auto launch = [&]() {
+        if (D->is_complex) launch_product<CplxOps>(D, X, x_stride, Y, y_stride, mu, numbering, st);
+        else launch_product<RealOps>(D, X, x_stride, Y, y_stride, mu, numbering, st);
+    };
+    // Small operators (the per-GPU share of a distributed run, Krylov loops on fixed buffers): a product is 4-6 short launches;
+    // the second request for the SAME product (buffers, stream) is captured as a hipGraph and replayed afterwards.
+    static const bool graphs_on = !(getenv("HTOOL_PRODUCT_GRAPH") && std::string(getenv("HTOOL_PRODUCT_GRAPH")) == "0");
+    // Only on a stream the CALLER named: with stream = NULL the kernels run on the handle's own stream and are ordered against
+    // the caller's default-stream work by the legacy default stream's implicit synchronisation -- which a graph launch does not take part in.
+    const bool graphable = graphs_on && !D->phase_timing && D->row_size <= 300000 && stream != nullptr;
+    if (!graphable) { launch(); return; }
+    ProductGraph &g = D->graph;
+    const bool same = g.x == X && g.y == Y && g.x_stride == x_stride && g.y_stride == y_stride && g.mu == mu && g.numbering == numbering && g.stream == st;
+    if (same && g.exec) {
+        HIP_OK(hipGraphLaunch(g.exec, st));
+        g.replays++;
+        return;
+    }
+    if (!same) {
+        drop_product_graph(D);
+        g.x = X; g.y = Y; g.x_stride = x_stride; g.y_stride = y_stride; g.mu = mu; g.numbering = numbering; g.stream = st;
+        launch();
+        return;
+    }
+    hipGraph_t captured = nullptr;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { // (a stream that cannot be captured: stay eager)
+        (void)hipGetLastError();
+        launch();
+        return;
+    }
+    try {
+        launch();
+    } catch (...) {
+        (void)hipStreamEndCapture(st, &captured);
+        if (captured) (void)hipGraphDestroy(captured);
+        throw;
+    }
+    HIP_OK(hipStreamEndCapture(st, &captured));
+    const hipError_t e = hipGraphInstantiate(&g.exec, captured, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(captured);
+    if (e != hipSuccess) { (void)hipGetLastError(); g.exec = nullptr; g.x = nullptr; launch(); return; }
+    HIP_OK(hipGraphLaunch(g.exec, st));
 }
 
 void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream) {
@@ -358,6 +406,7 @@ void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
 
 void device_set_phase_timing(const HMatrix &H, bool on) {
     HM_CHECK(H.dev != nullptr, "H-matrix has no device data");
+    drop_product_graph(H.dev);
     H.dev->phase_timing = on;
 }
 
@@ -404,6 +453,7 @@ int64_t device_resident_bytes(const HMatrix &H) {
 void device_free(DeviceHMatrix *D) {
     if (!D) return;
     (void)hipSetDevice(D->device);
+    drop_product_graph(D);
     for (auto &B : D->batches) {
         (void)hipFree(B.panelB); (void)hipFree(B.panelA); (void)hipFree(B.cidxB); (void)hipFree(B.oidxA);
         if (B.zidxB) (void)hipFree(B.zidxB);

@@ -64,7 +64,20 @@ struct BatchTables {
     int64_t r_end = 0;   // end of the part of the R workspace this batch's layout refers to
 };
 
+// the launches of one product, captured as a hipGraph the second time the same product (same buffers, same stream) is asked
+// for and replayed from then on: a Krylov loop or a distributed step on fixed buffers then costs one graph launch
+struct ProductGraph {
+    const void *x = nullptr;
+    void *y = nullptr;
+    long long x_stride = 0, y_stride = 0;
+    int mu = 0, numbering = -1;
+    hipStream_t stream = nullptr;
+    hipGraphExec_t exec = nullptr;
+    long long replays = 0;
+};
+
 struct DeviceHMatrix {
+    ProductGraph graph;
     std::recursive_mutex mu; // serialises the products of this handle issued from several host threads (shared workspace)
     int device = 0;
     std::vector<BatchTables> tabs;

@@ -137,7 +137,8 @@ static DistDeviceState *dist_state(htool_distributed *d, int mu) {
 
 // Y_local = A[rows of this rank, :] X with X given by its local slices: column c of X_local holds this rank's part
 // (source partition `rank`, cluster numbering) at X_local + c * ldx; Y_local + c * ldy receives the rank's rows.
-static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_t ldx, void *Y_local, int64_t ldy, int mu, hipStream_t st) {
+static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_t ldx, void *Y_local, int64_t ldy, int mu, hipStream_t caller_stream) {
+    hipStream_t st = caller_stream;
     const HMatrix &H = d->hmat->H;
     const size_t es = H.is_complex ? 16 : 8;
     const int P = d->comm.size, rank = d->comm.rank;
@@ -145,7 +146,7 @@ static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_
     HM_CHECK(H.dev != nullptr, "H-matrix has no device data");
     if (!st) st = H.dev->stream; // the exchange and the product have to share one stream
     if (P == 1 && !d->comm.rccl) { // one rank owns everything and there is no RCCL handle: the slice is the whole vector
-        device_matmat_device(H, X_local, (long long)ldx, Y_local, (long long)ldy, mu, 1, st);
+        device_matmat_device(H, X_local, (long long)ldx, Y_local, (long long)ldy, mu, 1, caller_stream);
         return;
     }
     RcclComm *rc = static_cast<RcclComm *>(d->comm.rccl);
@@ -169,7 +170,7 @@ static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_
         else hipLaunchKernelGGL(compact_slices_kernel<double>, grid, block, 0, st, (const double *)s->recv, (double *)s->x_full, s->counts, s->displs, s->pad, mu, (long long)ns);
         HIP_OK(hipGetLastError());
     }
-    device_matmat_device(H, s->x_full, (long long)ns, Y_local, (long long)ldy, mu, 1, st);
+    device_matmat_device(H, s->x_full, (long long)ns, Y_local, (long long)ldy, mu, 1, caller_stream); // (NULL: the operator's own stream, = st)
 }
 
 extern "C" {
