@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--symmetric", choices=["full", "one-triangle"], default=None,
                     help="build with symmetry 'S' / UPLO 'L' (single GPU only): 'full' stores both triangles (the default engine "
                          "layout), 'one-triangle' stores the lower triangle only and uses every leaf twice in a fused sweep")
+    ap.add_argument("--no-phase-timing", action="store_true", help="do not record the per-phase HIP events (the roofline object is then empty); "
+                                                                    "lets the library replay repeated products as a hipGraph")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the error against sampled exact rows is always reported)")
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON): libraries that chat on stdout (RCCL prints a version banner when a
@@ -276,7 +278,7 @@ def main():
         Htool.recompression(H)
         torch.cuda.synchronize()
         t_recompress = time.time() - t0
-    H.set_phase_timing(True)  # HIP events around every launch of a product (the roofline object needs them)
+    H.set_phase_timing(not args.no_phase_timing)  # HIP events around every launch of a product (the roofline object needs them)
     leaves = H.leaves()
     n_rows = H.shape[0]
     ab = algorithmic_bytes(leaves, n, n_rows, elem)

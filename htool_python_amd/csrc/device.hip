@@ -233,8 +233,8 @@ static void ensure_w16(DeviceHMatrix *D) {
             Reduce16 r;
             r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)sizeof(double);
             r.out_base = x.out_begin;
-            r.ld = sg.ld_last; r.nrows = sg.nrows_t; r.ncols = sg.ncols; r.pad_ = 0;
-            items.push_back(r);
+            r.ld = sg.ld_last; r.nrows = sg.nrows_t; r.ncols = sg.ncols;
+            for (r.row0 = 0; r.row0 < r.nrows; r.row0 += 16) items.push_back(r); // one work item per 16 rows
         }
     }
     D->red16 = upload(items);
@@ -249,7 +249,7 @@ static void launch_sweep16(DeviceHMatrix *D, const double *x, long long x_stride
     hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
     const bool timing = D->phase_timing;
     if (timing) HIP_OK(hipEventRecord(ev[0], st));
-    if (Ns) hipLaunchKernelGGL(gather_x16_kernel, dim3((unsigned)(((long long)Ns * 16 + 255) / 256)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_s : (const int *)nullptr, W16, Ns, nr);
+    if (Ns) hipLaunchKernelGGL(gather_x16_kernel, dim3((unsigned)((Ns + 63) / 64)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_s : (const int *)nullptr, W16, Ns, nr);
     if (timing) HIP_OK(hipEventRecord(ev[1], st));
     if (D->nA) hipLaunchKernelGGL(tile_gemm_tall16, dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, W16);
     if (timing) HIP_OK(hipEventRecord(ev[2], st));

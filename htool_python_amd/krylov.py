@@ -73,16 +73,16 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
                 t = cs[i] * col[i] + sn[i] * col[i + 1]
                 col[i + 1] = -np.conj(sn[i]) * col[i] + cs[i] * col[i + 1]
                 col[i] = t
-            a, b = col[j], col[j + 1]
-            denom = math.sqrt(abs(a) ** 2 + abs(b) ** 2)
+            ha, hb = col[j], col[j + 1]
+            denom = math.sqrt(abs(ha) ** 2 + abs(hb) ** 2)
             if denom == 0.0:
                 cs[j], sn[j] = 1.0, 0.0
-            elif a == 0:
+            elif ha == 0:
                 cs[j], sn[j] = 0.0, 1.0
-            else:  # c real, s complex: [c s; -conj(s) c] [a; b] = [r; 0]
-                cs[j] = abs(a) / denom
-                sn[j] = (a / abs(a)) * np.conj(b) / denom
-            col[j] = cs[j] * a + sn[j] * b
+            else:  # c real, s complex: [c s; -conj(s) c] [ha; hb] = [r; 0]
+                cs[j] = abs(ha) / denom
+                sn[j] = (ha / abs(ha)) * np.conj(hb) / denom
+            col[j] = cs[j] * ha + sn[j] * hb
             col[j + 1] = 0.0
             R[: j + 2, j] = col
             g[j + 1] = -np.conj(sn[j]) * g[j]
