@@ -135,6 +135,22 @@ TileSet make_tiles(const ClusterTree &T, int root_node, int tile_max) {
     return ts;
 }
 
+void assign_tile_groups(const ClusterTree &T, int root_node, const TileSet &tiles, int group_positions, std::vector<int> &group) {
+    group.assign((size_t)tiles.count(), 0);
+    int next = 0;
+    std::vector<int> st{root_node};
+    while (!st.empty()) { // depth-first in offset order, as make_tiles numbers the tiles
+        const int id = st.back();
+        st.pop_back();
+        if (T.is_leaf(id) || T.size[id] <= group_positions) {
+            for (int c = tiles.node_tile_begin[id]; c < tiles.node_tile_end[id]; c++) group[c] = next;
+            if (tiles.node_tile_end[id] > tiles.node_tile_begin[id]) next++;
+        } else {
+            for (int c = T.n_child[id] - 1; c >= 0; c--) st.push_back(T.first_child[id] + c);
+        }
+    }
+}
+
 HMatrix::~HMatrix() {
     if (dev) device_free(dev);
 }

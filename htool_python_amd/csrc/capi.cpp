@@ -281,6 +281,11 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     H.tile_max = H.is_complex ? 64 : 128;
     H.rtiles = make_tiles(*T, H.t_root, H.tile_max);
     H.ctiles = make_tiles(*S, H.s_root, H.tile_max);
+    {
+        int gp = 512; // source positions per phase-A group (HTOOL_PHASE_A_GROUP=1: one tile per group, the round-1 scheme)
+        if (const char *e = getenv("HTOOL_PHASE_A_GROUP")) gp = std::max(1, atoi(e));
+        assign_tile_groups(*S, H.s_root, H.ctiles, gp, H.ctile_group);
+    }
     h->tch = T->handle(H.t_root);
     h->sch = S->handle(H.s_root);
     double t0 = wall_seconds();
@@ -337,7 +342,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     HMatrix &d = c->H;
     d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
     d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size; d.local_numbering = s.local_numbering; d.one_triangle = s.one_triangle;
-    d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.blocks = s.blocks; d.r_elems = s.r_elems;
+    d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.ctile_group = s.ctile_group; d.blocks = s.blocks; d.r_elems = s.r_elems;
     d.build_seconds = s.build_seconds; d.n_batches = s.n_batches;
     c->tch = h->tch; c->sch = h->sch;
     device_clone(s, d);

@@ -106,7 +106,7 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     if (timing) HIP_OK(hipEventRecord(ev[0], st));
     if (Ns) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((Ns + 255) / 256), dim3(256), 0, st, (const T *)x_dev, x_stride, in_user ? D->perm_s : (const int *)nullptr, W, ws, Ns, NR);
     if (timing) HIP_OK(hipEventRecord(ev[1], st));
-    if (D->nA) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W, ws, ws, 0LL);
+    if (D->nA) hipLaunchKernelGGL((tile_gemv_tall_grouped<Ops, 16, NR>), dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (const T *)W, W, ws, ws);
     if (timing) HIP_OK(hipEventRecord(ev[2], st));
     if (D->nA2) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nA2), dim3(256), 0, st, D->tilesA2, D->segs, (const T *)W, W, ws, ws, ws);
     if (timing) HIP_OK(hipEventRecord(ev[3], st));

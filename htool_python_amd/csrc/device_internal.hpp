@@ -34,6 +34,8 @@ struct GSeg {
     const int *oidx = nullptr;      // tall panels: output index of every row (null: the tile's omap / out_begin)
     const int *zidx = nullptr;      // one-triangle storage: per column, where its transposed dot product goes in W (-1: nowhere);
                             // for the transposed use of a tall panel: per row, the index in W of its coefficient
+    int flush_from = 0;     // phase A, grouped source tiles: rows >= this are written out after this tile's panel (the others go on accumulating)
+    int pad_ = 0;
 };
 
 struct GTile {
@@ -55,7 +57,7 @@ struct DevBatch {
 
 // what table assembly / introspection needs to remember about a packed batch (host copies)
 struct BatchTables {
-    std::vector<int> b_ncols, a_nrows;
+    std::vector<int> b_ncols, a_nrows, a_flush;
     std::vector<int64_t> b_pbase, b_cbase, a_pbase, a_obase;
     std::vector<BatchLayout::Reduce> reduces;
     std::vector<BatchLayout::Reduce> z_reduces;

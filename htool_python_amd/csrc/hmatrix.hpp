@@ -51,6 +51,10 @@ struct TileSet {
 };
 
 TileSet make_tiles(const ClusterTree &T, int root_node, int tile_max);
+// Source tiles are streamed in GROUPS by phase A: a group is the tiles of one cluster node of at most group_positions points
+// (or of one leaf).  Every low-rank leaf whose source cluster lies inside a group gets its t = V x completed by ONE
+// workgroup; leaves above get one partial sum per group (not per tile).  group[c] = group of tile c, numbered in tile order.
+void assign_tile_groups(const ClusterTree &T, int root_node, const TileSet &tiles, int group_positions, std::vector<int> &group);
 
 // host description of what one pack batch needs (computed by layout.cpp, consumed by device.hip)
 struct BatchLayout {
@@ -65,6 +69,7 @@ struct BatchLayout {
     std::vector<int> a_nrows;      // (leaf,k) rows contributed by this batch
     std::vector<int64_t> a_pbase;  // element offset in panelA
     std::vector<int64_t> a_obase;  // offset of the tile's output-index list in oidxA
+    std::vector<int> a_flush;      // rows >= this have their sums written out after the tile (0: all of them, the group ends here)
     int64_t panelA_elems = 0, oidxA_elems = 0;
     // phase A2 tiles: (partial panel offset in W, ld, rows, cols, output base in W)
     struct Reduce { int64_t w_panel; int ld; int nrows; int ncols; int64_t out_base; };
@@ -117,6 +122,7 @@ struct HMatrix {
     BuildParams params;
     int tile_max = 128;
     TileSet rtiles, ctiles;
+    std::vector<int> ctile_group;   // group of every source tile (phase A streams a group per workgroup)
     std::vector<BlockRec> blocks;
     int64_t r_elems = 0;            // size of region R of W
     double build_seconds = 0;

@@ -68,6 +68,8 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
     L.a_nrows.assign(nct, 0);
     L.a_pbase.assign(nct, 0);
     L.a_obase.assign(nct, 0);
+    L.a_flush.assign(nct, 0);
+    const std::vector<int> &gid = H.ctile_group;
     int64_t pa = 0, oa = 0;
     for (int c = 0; c < nct; c++) {
         int leaf = H.ctiles.leaf_of_tile[c];
@@ -84,6 +86,17 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
     }
     L.panelA_elems = pa;
     L.oidxA_elems = oa;
+    // rows a tile shares with its successor in the same group keep accumulating; the others are written out after it.  The
+    // shared rows are those of the common ancestors: everything up to and including the lowest one
+    for (int c = 0; c + 1 < nct; c++) {
+        if (gid[c] != gid[c + 1]) continue; // last tile of its group: all rows are written
+        int a = H.ctiles.leaf_of_tile[c], b = H.ctiles.leaf_of_tile[c + 1];
+        while (a != b) {
+            if (S.depth[a] >= S.depth[b]) a = S.parent[a];
+            else b = S.parent[b];
+        }
+        L.a_flush[c] = sbase[a] + Ks[a];
+    }
 
     // ---- region R of W: t vectors, and partial panels for source nodes spanning several tiles
     const int64_t r_start = round_up(H.col_size + 1, 2); // W index of R[0]
@@ -94,7 +107,9 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
         if (Ks[id] == 0) continue;
         tb[id] = cur;
         cur += Ks[id];
-        int P = H.ctiles.node_tile_end[id] - H.ctiles.node_tile_begin[id];
+        // partial sums: one per GROUP of source tiles the node spans (a node inside one group is summed by that group's workgroup)
+        const int t0 = H.ctiles.node_tile_begin[id], t1 = H.ctiles.node_tile_end[id];
+        const int P = t1 > t0 ? gid[t1 - 1] - gid[t0] + 1 : 0;
         if (P > 1) {
             cur = (cur + 1) / 2 * 2;
             ldp[id] = round_up(Ks[id], vec_rows);
