@@ -89,10 +89,60 @@ void visit(const Ctx &c, int t, int s) {
 
 } // namespace
 
+// The recursion is expanded sequentially down to a few hundred sub-problems, which are then solved by all threads; the pieces
+// are concatenated in the order of the sequential traversal, so the queues are the same for every thread count.
 void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int s_root,
                       std::vector<BlockRec> &adm, std::vector<BlockRec> &dns) {
-    Ctx c{T, S, P, adm, dns};
-    visit(c, t_root, s_root < 0 ? 0 : s_root);
+    struct Item { int kind, t, s; BlockRec b; }; // kind 0: admissible block, 1: dense block, 2: sub-problem (t, s) still to visit
+    std::vector<Item> items;
+    items.push_back({2, t_root, s_root < 0 ? 0 : s_root, BlockRec()});
+    const size_t want = 512;
+    for (int pass = 0; pass < 12; pass++) { // one level of the traversal per pass, order preserved
+        size_t open = 0;
+        for (const Item &it : items) open += it.kind == 2;
+        if (open == 0 || open >= want) break;
+        std::vector<Item> next;
+        next.reserve(items.size() * 2);
+        for (const Item &it : items) {
+            if (it.kind != 2) { next.push_back(it); continue; }
+            // one step of visit(): what it would emit or recurse into, in its order
+            std::vector<BlockRec> a, d;
+            Ctx c{T, S, P, a, d};
+            const int t = it.t, s = it.s;
+            if (T.size[t] == 0 || S.size[s] == 0) continue;
+            if (P.store_one_triangle) {
+                if (P.uplo == 'L' && S.offset[s] >= T.offset[t] + T.size[t]) continue;
+                if (P.uplo == 'U' && T.offset[t] >= S.offset[s] + S.size[s]) continue;
+            }
+            if (admissible(c, t, s) && T.depth[t] >= P.min_target_depth && S.depth[s] >= P.min_source_depth) { next.push_back({0, t, s, make_block(c, t, s)}); continue; }
+            const bool lt = T.is_leaf(t), ls = S.is_leaf(s);
+            if (lt && ls) { next.push_back({1, t, s, make_block(c, t, s)}); continue; }
+            if (ls || (!lt && T.size[t] > S.size[s])) {
+                for (int x = 0; x < T.n_child[t]; x++) next.push_back({2, T.first_child[t] + x, s, BlockRec()});
+            } else if (lt || S.size[s] > T.size[t]) {
+                for (int y = 0; y < S.n_child[s]; y++) next.push_back({2, t, S.first_child[s] + y, BlockRec()});
+            } else {
+                for (int x = 0; x < T.n_child[t]; x++)
+                    for (int y = 0; y < S.n_child[s]; y++) next.push_back({2, T.first_child[t] + x, S.first_child[s] + y, BlockRec()});
+            }
+        }
+        items.swap(next);
+    }
+    std::vector<std::vector<BlockRec>> pa(items.size()), pd(items.size());
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long i = 0; i < (long)items.size(); i++) {
+        if (items[i].kind != 2) continue;
+        Ctx c{T, S, P, pa[i], pd[i]};
+        visit(c, items[i].t, items[i].s);
+    }
+    for (size_t i = 0; i < items.size(); i++) {
+        if (items[i].kind == 0) adm.push_back(items[i].b);
+        else if (items[i].kind == 1) dns.push_back(items[i].b);
+        else {
+            adm.insert(adm.end(), pa[i].begin(), pa[i].end());
+            dns.insert(dns.end(), pd[i].begin(), pd[i].end());
+        }
+    }
 }
 
 void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, const BlockRec &b,

@@ -530,6 +530,8 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     auto reloc = [&](const void *p) -> const void * {
         if (!p) return nullptr;
         for (auto &r : map) if ((const char *)p >= r.old_lo && (const char *)p < r.old_hi) return r.neu + ((const char *)p - r.old_lo);
+        // (an empty segment may point one past the end of its buffer: never dereferenced, keep it at the same place of the copy)
+        for (auto &r : map) if ((const char *)p == r.old_hi) return r.neu + (r.old_hi - r.old_lo);
         throw Error("device_clone: dangling table pointer");
     };
     // segment table

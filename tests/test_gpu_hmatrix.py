@@ -537,3 +537,46 @@ def test_randomised_stress_short(built):
         assert mod.main(25.0, 3) == 0
     finally:
         os.environ.pop("HTOOL_BUILD_ARENA_MB", None)
+
+
+@pytest.mark.parametrize("case", ["binary_leaf12", "ternary_leaf40", "leaf300_multi_tile_leaves", "complex_leaf20", "one_triangle", "rect_partition"])
+def test_grouped_phase_a_equals_per_tile_scheme(built, oracle, monkeypatch, case):
+    """Phase A streams GROUPS of source tiles (a leaf inside a group gets its t = V x from one workgroup, leaves above one
+    partial per group).  HTOOL_PHASE_A_GROUP=1 builds the same operator with one tile per group (one partial per tile, the
+    round-1 scheme): same panels, other summation order -- the products agree to rounding, each is bitwise repeatable, and
+    both meet the dense operator."""
+    import Htool
+
+    O = oracle
+    np.random.seed(5)
+    cplx = case == "complex_leaf20"
+    n = 5000
+    leaf, children = {"binary_leaf12": (12, 2), "ternary_leaf40": (40, 3), "leaf300_multi_tile_leaves": (300, 2), "complex_leaf20": (20, 2),
+                      "one_triangle": (25, 2), "rect_partition": (30, 2)}[case]
+    T = O.points_in_sphere(n)
+    S = O.points_in_sphere(3100) + np.array([[0.3], [0.1], [0.0]]) if case == "rect_partition" else T
+    world = 3 if case == "rect_partition" else 1
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    tcl = b.create_cluster_tree(T, children, size_of_partition=world)
+    scl = tcl if S is T else b.create_cluster_tree(S, children)
+    sym = ("S", "L") if case == "one_triangle" else ("N", "N")
+    ys = []
+    for group in ("512", "1", "100000"):
+        monkeypatch.setenv("HTOOL_PHASE_A_GROUP", group)
+        if cplx:
+            H = Htool.ComplexHMatrixTreeBuilder(1e-5, 10.0, *sym).build(Htool.ComplexNativeGenerator("helmholtz", T, S, 5.0), tcl, scl)
+        else:
+            H = Htool.HMatrixTreeBuilder(1e-5, 10.0, *sym).build(Htool.NativeGenerator("laplace", T, S), tcl, scl, 1 if world > 1 else -1)
+        x = np.random.RandomState(1).rand(S.shape[1]) + (1j * np.random.RandomState(2).rand(S.shape[1]) if cplx else 0)
+        y = H * x
+        assert np.array_equal(y, H * x)
+        X = np.asfortranarray(np.stack([x, 2 * x, -x, x, x, 0.5 * x, x, x, x, 3 * x, x], axis=1))  # 11 columns: the 16-wide sweep (real), 8 + 2 + 1 (complex)
+        Y = H @ X
+        assert np.linalg.norm(Y[:, 0] - y) <= 1e-13 * np.linalg.norm(y) and np.linalg.norm(Y[:, 9] - 3 * y) <= 1e-13 * np.linalg.norm(y)
+        ys.append(y)
+        del H
+    assert np.linalg.norm(ys[0] - ys[1]) <= 1e-13 * np.linalg.norm(ys[1]) and np.linalg.norm(ys[2] - ys[1]) <= 1e-13 * np.linalg.norm(ys[1])
+    if world == 1:
+        ye = O.dense_matvec(O.K_HELMHOLTZ if cplx else O.K_LAPLACE, T, S, x, 5.0 if cplx else 0.0)
+        assert np.linalg.norm(ys[0] - ye) / np.linalg.norm(ye) < 1e-5

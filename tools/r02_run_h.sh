@@ -4,7 +4,7 @@ set -e
 export TMPDIR=/tmp
 O=gpurun_out/r02h
 mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/tests.log 2>&1
 echo "tests ok"
 for leaf in 100 16 10; do timeout -k 10 300 python bench.py --leaf $leaf --no-cpu-baseline > $O/bench_leaf$leaf.json 2> $O/bench_leaf$leaf.err; done
 echo "leaf ok"
