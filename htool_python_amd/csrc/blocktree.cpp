@@ -21,20 +21,23 @@ namespace hm {
 
 namespace {
 
+typedef std::pair<int, int> NodePair; // (target node, source node)
+
+// The traversal emits node pairs only (8 bytes); the full leaf records are materialised afterwards, by all threads.
 struct Ctx {
     const ClusterTree &T, &S;
     const BuildParams &P;
-    std::vector<BlockRec> &adm, &dns;
+    std::vector<NodePair> &adm, &dns;
 };
 
-BlockRec make_block(const Ctx &c, int t, int s) {
+BlockRec make_block(const ClusterTree &T, const ClusterTree &S, int t, int s) {
     BlockRec b;
     b.t_node = t;
     b.s_node = s;
-    b.t_off = c.T.offset[t];
-    b.m = c.T.size[t];
-    b.s_off = c.S.offset[s];
-    b.n = c.S.size[s];
+    b.t_off = T.offset[t];
+    b.m = T.size[t];
+    b.s_off = S.offset[s];
+    b.n = S.size[s];
     b.rank = -1;
     b.cap = 0;
     b.batch = -1;
@@ -61,7 +64,7 @@ void visit(const Ctx &c, int t, int s);
 void split(const Ctx &c, int t, int s) {
     const bool lt = c.T.is_leaf(t), ls = c.S.is_leaf(s);
     if (lt && ls) {
-        c.dns.push_back(make_block(c, t, s));
+        c.dns.push_back(NodePair(t, s));
         return;
     }
     if (ls || (!lt && c.T.size[t] > c.S.size[s])) {
@@ -81,10 +84,18 @@ void visit(const Ctx &c, int t, int s) {
         if (c.P.uplo == 'U' && c.T.offset[t] >= c.S.offset[s] + c.S.size[s]) return;
     }
     if (admissible(c, t, s) && c.T.depth[t] >= c.P.min_target_depth && c.S.depth[s] >= c.P.min_source_depth) {
-        c.adm.push_back(make_block(c, t, s));
+        c.adm.push_back(NodePair(t, s));
         return;
     }
     split(c, t, s);
+}
+
+// node pairs -> leaf records appended to out (all threads)
+void materialise(const ClusterTree &T, const ClusterTree &S, const std::vector<NodePair> &ids, std::vector<BlockRec> &out) {
+    const size_t base = out.size();
+    out.resize(base + ids.size());
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)ids.size(); i++) out[base + i] = make_block(T, S, ids[i].first, ids[i].second);
 }
 
 } // namespace
@@ -93,9 +104,9 @@ void visit(const Ctx &c, int t, int s) {
 // are concatenated in the order of the sequential traversal, so the queues are the same for every thread count.
 void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, int t_root, int s_root,
                       std::vector<BlockRec> &adm, std::vector<BlockRec> &dns) {
-    struct Item { int kind, t, s; BlockRec b; }; // kind 0: admissible block, 1: dense block, 2: sub-problem (t, s) still to visit
+    struct Item { int kind, t, s; }; // kind 0: admissible pair, 1: dense pair, 2: sub-problem (t, s) still to visit
     std::vector<Item> items;
-    items.push_back({2, t_root, s_root < 0 ? 0 : s_root, BlockRec()});
+    items.push_back({2, t_root, s_root < 0 ? 0 : s_root});
     const size_t want = 512;
     for (int pass = 0; pass < 12; pass++) { // one level of the traversal per pass, order preserved
         size_t open = 0;
@@ -106,7 +117,7 @@ void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildPar
         for (const Item &it : items) {
             if (it.kind != 2) { next.push_back(it); continue; }
             // one step of visit(): what it would emit or recurse into, in its order
-            std::vector<BlockRec> a, d;
+            std::vector<NodePair> a, d;
             Ctx c{T, S, P, a, d};
             const int t = it.t, s = it.s;
             if (T.size[t] == 0 || S.size[s] == 0) continue;
@@ -114,41 +125,47 @@ void build_block_tree(const ClusterTree &T, const ClusterTree &S, const BuildPar
                 if (P.uplo == 'L' && S.offset[s] >= T.offset[t] + T.size[t]) continue;
                 if (P.uplo == 'U' && T.offset[t] >= S.offset[s] + S.size[s]) continue;
             }
-            if (admissible(c, t, s) && T.depth[t] >= P.min_target_depth && S.depth[s] >= P.min_source_depth) { next.push_back({0, t, s, make_block(c, t, s)}); continue; }
+            if (admissible(c, t, s) && T.depth[t] >= P.min_target_depth && S.depth[s] >= P.min_source_depth) { next.push_back({0, t, s}); continue; }
             const bool lt = T.is_leaf(t), ls = S.is_leaf(s);
-            if (lt && ls) { next.push_back({1, t, s, make_block(c, t, s)}); continue; }
+            if (lt && ls) { next.push_back({1, t, s}); continue; }
             if (ls || (!lt && T.size[t] > S.size[s])) {
-                for (int x = 0; x < T.n_child[t]; x++) next.push_back({2, T.first_child[t] + x, s, BlockRec()});
+                for (int x = 0; x < T.n_child[t]; x++) next.push_back({2, T.first_child[t] + x, s});
             } else if (lt || S.size[s] > T.size[t]) {
-                for (int y = 0; y < S.n_child[s]; y++) next.push_back({2, t, S.first_child[s] + y, BlockRec()});
+                for (int y = 0; y < S.n_child[s]; y++) next.push_back({2, t, S.first_child[s] + y});
             } else {
                 for (int x = 0; x < T.n_child[t]; x++)
-                    for (int y = 0; y < S.n_child[s]; y++) next.push_back({2, T.first_child[t] + x, S.first_child[s] + y, BlockRec()});
+                    for (int y = 0; y < S.n_child[s]; y++) next.push_back({2, T.first_child[t] + x, S.first_child[s] + y});
             }
         }
         items.swap(next);
     }
-    std::vector<std::vector<BlockRec>> pa(items.size()), pd(items.size());
+    std::vector<std::vector<NodePair>> pa(items.size()), pd(items.size());
 #pragma omp parallel for schedule(dynamic, 1)
     for (long i = 0; i < (long)items.size(); i++) {
         if (items[i].kind != 2) continue;
         Ctx c{T, S, P, pa[i], pd[i]};
         visit(c, items[i].t, items[i].s);
     }
+    std::vector<NodePair> ia, id;
     for (size_t i = 0; i < items.size(); i++) {
-        if (items[i].kind == 0) adm.push_back(items[i].b);
-        else if (items[i].kind == 1) dns.push_back(items[i].b);
+        if (items[i].kind == 0) ia.push_back(NodePair(items[i].t, items[i].s));
+        else if (items[i].kind == 1) id.push_back(NodePair(items[i].t, items[i].s));
         else {
-            adm.insert(adm.end(), pa[i].begin(), pa[i].end());
-            dns.insert(dns.end(), pd[i].begin(), pd[i].end());
+            ia.insert(ia.end(), pa[i].begin(), pa[i].end());
+            id.insert(id.end(), pd[i].begin(), pd[i].end());
         }
     }
+    materialise(T, S, ia, adm);
+    materialise(T, S, id, dns);
 }
 
 void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildParams &P, const BlockRec &b,
                         std::vector<BlockRec> &adm, std::vector<BlockRec> &dns) {
-    Ctx c{T, S, P, adm, dns};
+    std::vector<NodePair> ia, id;
+    Ctx c{T, S, P, ia, id};
     split(c, b.t_node, b.s_node);
+    for (const NodePair &q : ia) adm.push_back(make_block(T, S, q.first, q.second));
+    for (const NodePair &q : id) dns.push_back(make_block(T, S, q.first, q.second));
 }
 
 TileSet make_tiles(const ClusterTree &T, int root_node, int tile_max) {
