@@ -1,6 +1,7 @@
 """What every rank of a P-GPU run has to do, measured one rank at a time on ONE GPU (same tree, same builds as
 bench.py --gpus P): panels per rank, build time, product time (HIP events, cluster numbering in and out)."""
-import json, sys, time
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, Htool
 from htool_python_amd.workloads import points_in_sphere, algorithmic_bytes
 
