@@ -117,6 +117,9 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
         if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 2>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
         t += cnt[1];
         if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 16, NR, 4>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
+        t += cnt[2];
+        // tiles of at most 8 lanes (16 real rows: the reference's default leaf size 10): eight columns per wave instruction, batches of 8 loads
+        if (cnt[3]) hipLaunchKernelGGL((tile_gemv_wide<Ops, 8, NR, 8>), dim3(cnt[3]), dim3(256), 0, st, t, D->segs, (const T *)W, out, ws, out_stride);
     };
     if (D->one_triangle) {
         // fused sweep: y (cluster numbering) and the transposed dot products of every column, then the transposed
@@ -131,7 +134,8 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
                 t += cnt[0];
                 if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2, NR>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
                 t += cnt[1];
-                if (cnt[2]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4, NR>), dim3(cnt[2]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
+                // (the fused kernel has no 8-column class: the tiles of classes 2 and 3 are consecutive and both fit its F = 4 form)
+                if (cnt[2] + cnt[3]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4, NR>), dim3(cnt[2] + cnt[3]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
             };
             if (D->splitB > 1 && D->nB_split) { // small operator: column slices of the row tiles, summed in slice order
                 launch_wide_sym(D->tilesB_split, D->cntBs, (T *)D->ypart, (long long)D->splitB * D->ypart_stride);
@@ -487,7 +491,7 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     D->nB = S->nB; D->nA = S->nA; D->nA2 = S->nA2; D->splitB = S->splitB; D->nB_split = S->nB_split;
     D->one_triangle = S->one_triangle; D->conj_transposed = S->conj_transposed; D->nAT = S->nAT; D->nZ = S->nZ; D->n_zd_tiles = S->n_zd_tiles;
     D->ycl_stride = S->ycl_stride; D->ypart_stride = S->ypart_stride; D->W_elems = S->W_elems; D->rhs_cap = S->rhs_cap;
-    for (int c = 0; c < 3; c++) { D->cntB[c] = S->cntB[c]; D->cntBs[c] = S->cntBs[c]; }
+    for (int c = 0; c < 4; c++) { D->cntB[c] = S->cntB[c]; D->cntBs[c] = S->cntBs[c]; }
     D->n_source = S->n_source; D->n_target = S->n_target; D->row_off = S->row_off; D->row_size = S->row_size; D->table_bytes = S->table_bytes;
     D->batches.resize(S->batches.size());
     for (size_t b = 0; b < S->batches.size(); b++) D->batches[b].bytes = S->batches[b].bytes;

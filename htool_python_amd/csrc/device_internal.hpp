@@ -104,7 +104,7 @@ struct DeviceHMatrix {
     int n_zd_tiles = 0;
     void *ycl = nullptr;
     long long ycl_stride = 0;       // elements between the accumulators of consecutive right-hand sides
-    int cntB[3] = {0, 0, 0}, cntBs[3] = {0, 0, 0}; // tiles per class of the wide kernel (F = 1, 2, 4 columns per wave instruction)
+    int cntB[4] = {0, 0, 0, 0}, cntBs[4] = {0, 0, 0, 0}; // tiles per class of the wide kernel (F = 1, 2, 4, 8 columns per wave instruction)
     GTile *tilesB_split = nullptr;
     void *ypart = nullptr;
     long long ypart_stride = 0;

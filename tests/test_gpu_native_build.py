@@ -184,6 +184,12 @@ def test_full_size_configs_by_properties(built, oracle, n, eps, kind, p0, leaf):
         assert np.linalg.norm(blk - exact) <= 10 * eps * np.linalg.norm(exact)
     # CPU leaf loop on a sampled subset of the device's own panels
     assert single_leaf_product_checks(H, cl, cl, dtype, n_sources=3, n_targets=12) >= 18
+    # independent of the C++ oracle: 200 sampled admissible leaves against the explicit-residual numpy ACA, the SVD
+    # epsilon-rank and the exact block (oracle/independent.py)
+    from tests.helpers import independent_leaf_checks
+
+    stats = independent_leaf_checks(H, pts, pts, kind, p0, eps, n_sample=200, max_block=500, seed=1)
+    assert stats["leaves"] == 200
     del H
     Htool.release_workspace()
 
