@@ -1,7 +1,7 @@
 """Derive HBM bytes per launch from the two rocprofv3 PMC passes committed next to this file.
 
-    python profiles/derive_pmc_traffic.py profiles/r01_pmc_fetch_size_counter_collection.csv \
-        profiles/r01_pmc_write_size_counter_collection.csv > profiles/r01_pmc_hbm_traffic_1m_laplace.json
+    python profiles/derive_pmc_traffic.py profiles/r02_pmc_fetch_size_counter_collection.csv \
+        profiles/r02_pmc_write_size_counter_collection.csv > profiles/r02_pmc_hbm_traffic_1m_laplace.json
 
 The passes are separate runs (`rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py
 --steps 3 --warmup 1 --no-cpu-baseline`, then the same with WRITE_SIZE).  rocprofv3 reports KiB; on gfx950 FETCH_SIZE
@@ -54,7 +54,17 @@ def main(fetch_csv, write_csv):
         return tot
 
     out["tile_gemv_wide_hbm_bytes_per_launch"] = hbm_bytes("hm::tile_gemv_wide<")
-    out["tile_gemv_tall_phaseA_hbm_bytes_per_launch"] = hbm_bytes("hm::tile_gemv_tall<")
+    out["tile_gemv_tall_phaseA_hbm_bytes_per_launch"] = hbm_bytes("hm::tile_gemv_tall_grouped<") or hbm_bytes("hm::tile_gemv_tall<")
+    # the fingerprint of the kernel sources these passes were taken on: bench.py quotes the traffic only while it matches
+    import os
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from bench import kernel_source_sha1
+
+        out["kernel_source_sha1"] = kernel_source_sha1()
+    except Exception:  # noqa: BLE001
+        out["kernel_source_sha1"] = None
     json.dump(out, sys.stdout, indent=1)
     print()
 
