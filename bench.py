@@ -187,6 +187,8 @@ def main():
                          "layout), 'one-triangle' stores the lower triangle only and uses every leaf twice in a fused sweep")
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record the per-phase HIP events (the roofline object is then empty); "
                                                                     "lets the library replay repeated products as a hipGraph")
+    ap.add_argument("--no-warm-build", action="store_true", help="skip the small untimed warm-up build (build_s then includes the one-off costs of a "
+                                                                  "process's first build: code objects, streams, first allocations)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the error against sampled exact rows is always reported)")
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON): libraries that chat on stdout (RCCL prints a version banner when a
@@ -233,6 +235,33 @@ def main():
     elem = 16 if is_complex else 8
     dtype = torch.complex128 if is_complex else torch.float64
     n = args.n
+
+    # the library's own account of the build (INFO line "native build timing: ...") goes into the JSON line
+    import logging
+
+    build_log = []
+
+    class _Keep(logging.Handler):
+        def emit(self, record):
+            if "native build timing" in record.getMessage():
+                build_log.append(record.getMessage())
+
+    logging.getLogger("Htool").addHandler(_Keep())
+    logging.getLogger("Htool").setLevel(logging.INFO)
+    if not args.no_warm_build:
+        # untimed warm-up, as for the products: a 20 000-point operator of the same kernel and dtype takes the one-off costs of a
+        # process's first build (code objects of the build kernels, streams, the first allocations) out of build_s
+        wp = points_in_sphere(20000, seed=1)
+        wcb = Htool.ClusterTreeBuilder()
+        wcb.set_maximal_leaf_size(args.leaf)
+        wcl = wcb.create_cluster_tree(wp, 2)
+        if is_complex:
+            Htool.ComplexHMatrixTreeBuilder(args.eps, args.eta, "N", "N").build(Htool.ComplexNativeGenerator(args.kernel, wp, wp, args.kappa), wcl, wcl)
+        else:
+            Htool.HMatrixTreeBuilder(args.eps, args.eta, "N", "N").build(Htool.NativeGenerator(args.kernel, wp, wp, {"laplace": 0.0, "inv_delta": 0.1}[args.kernel]), wcl, wcl)
+        torch.cuda.synchronize()
+        del wcl, wcb, wp
+        build_log.clear()
 
     pts = points_in_sphere(n, seed=0)
     t0 = time.time()
@@ -447,6 +476,8 @@ def main():
             "parallelism": f"rows{world}" if world > 1 else "single",
         },
         "build_s": t_build,
+        "build_warmed": not args.no_warm_build,
+        "build_breakdown": build_log[-1] if build_log else None,
         "recompression_s": t_recompress,
         "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,

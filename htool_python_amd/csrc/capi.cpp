@@ -375,19 +375,22 @@ static void check_numbering(const HMatrix &H, int numbering) {
     HM_CHECK(!in_user || H.s_root == 0, "user-numbered input needs an H-matrix built on the whole source cluster");
 }
 
-static void matvec_scaled(const HMatrix &H, const void *alpha, const void *x, const void *beta, void *y) {
-    const size_t n = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+static void check_trans(char trans) { HM_CHECK(trans == 'N' || trans == 'T' || trans == 'C', "H-matrix product: trans must be 'N', 'T' or 'C'"); }
+
+static void matvec_scaled(const HMatrix &H, char trans, const void *alpha, const void *x, const void *beta, void *y) {
+    // entries of the result: rows of H (trans = 'N') or its columns
+    const size_t n = trans == 'N' ? (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size) : (size_t)H.col_size;
     if (H.is_complex) {
         cplx a = alpha ? *(const cplx *)alpha : cplx(1), b = beta ? *(const cplx *)beta : cplx(0);
-        if (a == cplx(1) && b == cplx(0)) { device_matvec_host(H, x, y); return; }
+        if (a == cplx(1) && b == cplx(0)) { device_matvec_host(H, x, y, trans); return; }
         std::vector<cplx> t(n);
-        device_matvec_host(H, x, t.data());
+        device_matvec_host(H, x, t.data(), trans);
         axpby<cplx>(n, a, t.data(), b, (cplx *)y);
     } else {
         double a = alpha ? *(const double *)alpha : 1.0, b = beta ? *(const double *)beta : 0.0;
-        if (a == 1.0 && b == 0.0) { device_matvec_host(H, x, y); return; }
+        if (a == 1.0 && b == 0.0) { device_matvec_host(H, x, y, trans); return; }
         std::vector<double> t(n);
-        device_matvec_host(H, x, t.data());
+        device_matvec_host(H, x, t.data(), trans);
         axpby<double>(n, a, t.data(), b, (double *)y);
     }
 }
@@ -396,21 +399,22 @@ extern "C" {
 
 int htool_hmatrix_matvec(const htool_hmatrix *h, char trans, const void *alpha, const void *x, const void *beta, void *y) {
     API_BEGIN
-    HM_CHECK(trans == 'N', "H-matrix product: only trans='N' is implemented on the HIP path");
-    matvec_scaled(h->H, alpha, x, beta, y);
+    check_trans(trans);
+    matvec_scaled(h->H, trans, alpha, x, beta, y);
     API_END
 }
 int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, const void *X, int mu, const void *beta, void *Y) {
     API_BEGIN
-    HM_CHECK(trans == 'N', "H-matrix product: only trans='N' is implemented on the HIP path");
+    check_trans(trans);
     const HMatrix &H = h->H;
     const size_t es = H.is_complex ? 16 : 8;
-    const size_t nin = (size_t)H.col_size, nout = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+    size_t nin = (size_t)H.col_size, nout = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
+    if (trans != 'N') std::swap(nin, nout);
     bool plain;
     if (H.is_complex) plain = (!alpha || *(const cplx *)alpha == cplx(1)) && (!beta || *(const cplx *)beta == cplx(0));
     else plain = (!alpha || *(const double *)alpha == 1.0) && (!beta || *(const double *)beta == 0.0);
-    if (plain) device_matmat_host(H, X, mu, Y); // all right-hand sides in one sweep of the panels
-    else for (int c = 0; c < mu; c++) matvec_scaled(H, alpha, (const char *)X + c * nin * es, beta, (char *)Y + c * nout * es);
+    if (plain) device_matmat_host(H, X, mu, Y, trans); // all right-hand sides in one sweep of the panels
+    else for (int c = 0; c < mu; c++) matvec_scaled(H, trans, alpha, (const char *)X + c * nin * es, beta, (char *)Y + c * nout * es);
     API_END
 }
 int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream) {
@@ -418,6 +422,20 @@ int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64
     check_numbering(h->H, numbering);
     HM_CHECK(mu >= 1, "mu must be >= 1");
     device_matmat_device(h->H, X_dev, (long long)ldx, Y_dev, (long long)ldy, mu, numbering, stream);
+    API_END
+}
+int htool_hmatrix_matmat_device_trans(const htool_hmatrix *h, char trans, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream) {
+    API_BEGIN
+    check_trans(trans);
+    HM_CHECK(numbering >= 0 && numbering <= 3, "numbering must be 0 (user/user), 1 (cluster/cluster), 2 (user in, cluster out) or 3 (cluster in, user out)");
+    if (trans == 'N') check_numbering(h->H, numbering);
+    else { // x lives on the target side, y on the source side
+        const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
+        HM_CHECK(!in_user || h->H.t_root == 0, "user-numbered input of a transposed product needs an H-matrix built on the whole target cluster");
+        HM_CHECK(!out_user || h->H.s_root == 0, "user-numbered output of a transposed product needs an H-matrix built on the whole source cluster");
+    }
+    HM_CHECK(mu >= 1, "mu must be >= 1");
+    device_matmat_device(h->H, X_dev, (long long)ldx, Y_dev, (long long)ldy, mu, numbering, stream, trans);
     API_END
 }
 int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void *y_dev, int numbering, void *stream) {

@@ -6,6 +6,8 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 namespace hm {
 
@@ -15,6 +17,11 @@ typedef std::complex<double> cplx;
 enum LogLevel { LOG_CRITICAL = 0, LOG_ERROR = 1, LOG_WARNING = 2, LOG_DEBUG = 3, LOG_INFO = 4 };
 void log_message(int level, const std::string &msg);
 void set_log_sink(void (*sink)(int, const char *));
+// Messages of a helper thread are held back and emitted by the thread that owns the call: the sink may need a lock only that
+// thread can give up (the Python shim's sink takes the interpreter lock).
+struct DeferredLog { std::vector<std::pair<int, std::string>> held; };
+void defer_log_to(DeferredLog *d); // this thread's messages go to d from now on (nullptr: straight to the sink again)
+void flush_deferred(DeferredLog &d);
 
 struct Error : std::runtime_error {
     explicit Error(const std::string &m) : std::runtime_error(m) {}

@@ -23,8 +23,10 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <numeric>
+#include <thread>
 #include <type_traits>
 
 namespace hm {
@@ -130,12 +132,12 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
             const int cj = D->conj_transposed ? 1 : 0;
             auto launch_wide_sym = [&](const GTile *tiles, const int *cnt, T *dst, long long dst_stride) { // one launch per lane-packing class
                 const GTile *t = tiles;
-                if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 1, NR>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
+                if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 1, NR>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride, (const T *)W, ws);
                 t += cnt[0];
-                if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2, NR>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
+                if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2, NR>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride, (const T *)W, ws);
                 t += cnt[1];
                 // (the fused kernel has no 8-column class: the tiles of classes 2 and 3 are consecutive and both fit its F = 4 form)
-                if (cnt[2] + cnt[3]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4, NR>), dim3(cnt[2] + cnt[3]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride);
+                if (cnt[2] + cnt[3]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4, NR>), dim3(cnt[2] + cnt[3]), dim3(256), 0, st, t, D->segs, (const T *)W, W, dst, cj, ws, dst_stride, (const T *)W, ws);
             };
             if (D->splitB > 1 && D->nB_split) { // small operator: column slices of the row tiles, summed in slice order
                 launch_wide_sym(D->tilesB_split, D->cntBs, (T *)D->ypart, (long long)D->splitB * D->ypart_stride);
@@ -165,6 +167,40 @@ static void launch_sweep(DeviceHMatrix *D, const void *x_dev, long long x_stride
     if (timing) HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
     if (timing) D->nprod++;
+}
+
+// y = H^T x (conj: H^H x) for an operator that stores both triangles, with the kernels of the one-triangle product:
+//   x -> cluster numbering of the rows;  phase-B panels, transposed dot products only (z = U^T x per leaf, D^T x per dense leaf);
+//   sums of the z partials of target nodes spanning several row tiles;  phase-A panels transposed (y += V^T z);
+//   dense contributions added and y scattered to the caller's numbering, one workgroup per source tile.
+// Every sum has a fixed order: bitwise reproducible like the direct product.  At most four right-hand sides per sweep.
+template <typename Ops, int NR>
+static void launch_sweep_T(DeviceHMatrix *D, const void *x_dev, long long x_stride, void *y_dev, long long y_stride, int numbering, bool conj, hipStream_t st) {
+    typedef typename Ops::T T;
+    T *W = (T *)D->W;
+    const long long ws = D->W_elems, xs = D->xt_stride, ys = D->ycl_stride;
+    T *XT = (T *)D->xt, *ycl = (T *)D->ycl;
+    const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
+    const int cj = conj ? 1 : 0;
+    if (D->row_size) hipLaunchKernelGGL(gather_x_kernel<T>, dim3((D->row_size + 255) / 256), dim3(256), 0, st, (const T *)x_dev, x_stride, in_user ? D->perm_t + D->row_off : (const int *)nullptr, XT, xs, D->row_size, NR);
+    const T *Xrows = XT - D->row_off; // (the row tiles carry target positions of the whole cluster tree)
+    const bool split = D->splitB > 1 && D->nB_split;
+    const GTile *t = split ? D->tilesB_split : D->tilesB_cluster;
+    const int *cnt = split ? D->cntBs : D->cntB;
+    if (cnt[0]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 1, NR, false>), dim3(cnt[0]), dim3(256), 0, st, t, D->segs, (const T *)W, W, (T *)nullptr, cj, ws, 0LL, Xrows, xs);
+    t += cnt[0];
+    if (cnt[1]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 2, NR, false>), dim3(cnt[1]), dim3(256), 0, st, t, D->segs, (const T *)W, W, (T *)nullptr, cj, ws, 0LL, Xrows, xs);
+    t += cnt[1];
+    if (cnt[2] + cnt[3]) hipLaunchKernelGGL((tile_gemv_wide_sym<Ops, 4, NR, false>), dim3(cnt[2] + cnt[3]), dim3(256), 0, st, t, D->segs, (const T *)W, W, (T *)nullptr, cj, ws, 0LL, Xrows, xs);
+    if (D->nZ) hipLaunchKernelGGL((tile_gemv_tall<Ops, 16, NR>), dim3(D->nZ), dim3(256), 0, st, D->tilesZ, D->segs, (const T *)W, W, ws, ws, ws);
+    HIP_OK(hipMemsetAsync(ycl, 0, (size_t)NR * ys * sizeof(T), st));
+    if (D->nAT) {
+        if constexpr (NR == 1) hipLaunchKernelGGL((tile_gemv_tall_transposed<Ops>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, cj);
+        else hipLaunchKernelGGL((tile_gemv_tall_transposed_multi<Ops, NR>), dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const T *)W, ycl, cj, ws, ys);
+    }
+    if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym_kernel<T>, dim3(D->n_zd_tiles), dim3(128), 0, st, (const T *)ycl, (const T *)W, D->zd_ptr, D->zd_woff, D->zd_rows,
+                                          out_user ? D->perm_s : (const int *)nullptr, (T *)y_dev, NR, ys, ws, y_stride);
+    HIP_OK(hipGetLastError());
 }
 
 // forget the captured product (its kernel arguments point into tables / workspaces that are about to change)
@@ -208,9 +244,14 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     }
     if (D->W) (void)hipFree(D->W);
     D->W = nW;
-    if (D->one_triangle) {
+    if (D->one_triangle || D->transposable) {
         if (D->ycl) (void)hipFree(D->ycl);
         HIP_OK(dev_malloc(&D->ycl, (size_t)nr * std::max<long long>(D->ycl_stride, 1) * sizeof(T)));
+    }
+    if (D->transposable) {
+        if (D->xt) (void)hipFree(D->xt);
+        HIP_OK(dev_malloc(&D->xt, (size_t)nr * std::max<long long>(D->xt_stride, 1) * sizeof(T)));
+        HIP_OK(hipMemset(D->xt, 0, (size_t)nr * std::max<long long>(D->xt_stride, 1) * sizeof(T)));
     }
     if (D->splitB > 1) {
         if (D->ypart) (void)hipFree(D->ypart);
@@ -300,14 +341,83 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
 }
 
 // Y = H X for mu right-hand sides stored with the given strides (elements); mu = 1 is the matvec
-void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream) {
+// make the tables of the transposed product (once per operator): the slots of the transposed dot products are added to the
+// coefficient workspace, every index array is written again (the panels are not touched) and the product tables re-assembled
+void device_make_transposable(HMatrix &H) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
+    std::lock_guard<std::recursive_mutex> lock(D->mu);
+    if (H.transposable || H.one_triangle) return;
+    HIP_OK(hipSetDevice(D->device));
+    HIP_OK(hipDeviceSynchronize()); // products in flight (on any stream) still read the tables that are replaced below
+    std::vector<std::vector<int64_t>> per_batch(D->batches.size());
+    for (size_t i = 0; i < H.blocks.size(); i++) {
+        const BlockRec &b = H.blocks[i];
+        if (b.rank == 0) continue;
+        HM_CHECK(b.batch >= 0 && b.batch < (int)per_batch.size(), "internal error: leaf without a batch");
+        per_batch[b.batch].push_back((int64_t)i);
+    }
+    DeviceBuilder db(H, D);
+    const bool timing = D->phase_timing;
+    db.free_product_tables();
+    H.transposable = true;
+    H.r_elems = 0;
+    try {
+        for (size_t b = 0; b < per_batch.size(); b++) {
+            if (H.is_complex) db.reindex_batch<double2>(per_batch[b], (int)b);
+            else db.reindex_batch<double>(per_batch[b], (int)b);
+        }
+        if (H.is_complex) db.assemble<double2>();
+        else db.assemble<double>();
+    } catch (...) {
+        H.transposable = false; // (the operator is unusable after a failure here: an allocation failed between tables)
+        throw;
+    }
+    D->phase_timing = timing;
+}
+
+template <typename Ops>
+static void launch_product_T(DeviceHMatrix *D, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, bool conj, hipStream_t st) {
+    typedef typename Ops::T T;
+    int done = 0;
+    while (done < mu) {
+        const int left = mu - done;
+        const T *x = (const T *)X + (long long)done * x_stride;
+        T *y = (T *)Y + (long long)done * y_stride;
+        if (left >= 4) { launch_sweep_T<Ops, 4>(D, x, x_stride, y, y_stride, numbering, conj, st); done += 4; }
+        else if (left >= 2) { launch_sweep_T<Ops, 2>(D, x, x_stride, y, y_stride, numbering, conj, st); done += 2; }
+        else { launch_sweep_T<Ops, 1>(D, x, x_stride, y, y_stride, numbering, conj, st); done += 1; }
+    }
+}
+
+void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream, char trans) {
+    DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HM_CHECK(trans == 'N' || trans == 'T' || trans == 'C', "H-matrix product: trans must be 'N', 'T' or 'C'");
     // products of one handle share its coefficient workspace (and may re-allocate it): callers on several host threads are
     // serialised here (launches only; the kernels of two calls on ONE stream run in order anyway)
     std::lock_guard<std::recursive_mutex> lock(D->mu);
     HIP_OK(hipSetDevice(D->device));
     hipStream_t st = stream ? (hipStream_t)stream : D->stream;
+    if (trans == 'C' && !D->is_complex) trans = 'T';
+    if (trans != 'N' && D->one_triangle) {
+        // one triangle stored: H = H^T ('S') or H = H^H ('H'), the product with the stored operator is the answer
+        HM_CHECK((trans == 'T' && !D->conj_transposed) || (trans == 'C' && D->conj_transposed),
+                 "H-matrix product: for one-triangle storage only the transposition that leaves the operator unchanged is implemented ('T' for 'S', 'C' for 'H')");
+        trans = 'N';
+    }
+    if (trans != 'N') {
+        if (!H.transposable) device_make_transposable(const_cast<HMatrix &>(H)); // (a cache of tables, made under the handle's lock)
+        const int need_t = mu >= 4 ? 4 : mu >= 2 ? 2 : 1;
+        if (need_t > D->rhs_cap) {
+            HIP_OK(hipStreamSynchronize(st));
+            if (D->is_complex) ensure_rhs_capacity<double2>(D, need_t);
+            else ensure_rhs_capacity<double>(D, need_t);
+        }
+        if (D->is_complex) launch_product_T<CplxOps>(D, X, x_stride, Y, y_stride, mu, numbering, trans == 'C', st);
+        else launch_product_T<RealOps>(D, X, x_stride, Y, y_stride, mu, numbering, false, st);
+        return;
+    }
     const int need = D->one_triangle ? (mu >= 4 ? 4 : mu >= 2 ? 2 : 1) : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
     if (mu > 8 && !D->is_complex && !D->one_triangle && !D->W16 && mfma_sweep_enabled()) {
         HIP_OK(hipStreamSynchronize(st));
@@ -362,18 +472,20 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
     HIP_OK(hipGraphLaunch(g.exec, st));
 }
 
-void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream) {
-    device_matmat_device(H, x_dev, 0, y_dev, 0, 1, numbering, stream);
+void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream, char trans) {
+    device_matmat_device(H, x_dev, 0, y_dev, 0, 1, numbering, stream, trans);
 }
 
 // host API convention: a matrix built on the whole target (source) cluster takes/returns user numbering on
 // that side; one built on a partition works on its local slice in cluster order
-static int host_numbering(const HMatrix &H) {
-    const bool in_user = H.s_root == 0 && !H.local_numbering, out_user = H.t_root == 0 && !H.local_numbering;
+static int host_numbering(const HMatrix &H, char trans = 'N') {
+    bool in_user = H.s_root == 0 && !H.local_numbering, out_user = H.t_root == 0 && !H.local_numbering;
+    if (trans != 'N') std::swap(in_user, out_user); // x lives on the target side then
     return in_user ? (out_user ? 0 : 2) : (out_user ? 3 : 1);
 }
 
-void device_matvec_host(const HMatrix &H, const void *x, void *y) {
+void device_matvec_host(const HMatrix &H, const void *x, void *y, char trans) {
+    if (trans != 'N') { device_matmat_host(H, x, 1, y, trans); return; }
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     std::lock_guard<std::recursive_mutex> lock(D->mu); // x_tmp / y_tmp and the stream are per handle: one host product at a time
@@ -389,23 +501,21 @@ void device_matvec_host(const HMatrix &H, const void *x, void *y) {
 }
 
 // Y = H X on host buffers, X column-major n_source x mu (user numbering), all right-hand sides in one go
-void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y) {
+void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y, char trans) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     std::lock_guard<std::recursive_mutex> lock(D->mu);
     HIP_OK(hipSetDevice(D->device));
     const size_t es = D->esize;
     const bool whole = H.t_root == 0;
-    const size_t nin = (size_t)D->n_source, nout = (size_t)(whole ? D->n_target : D->row_size);
-    void *dX = nullptr, *dY = nullptr;
-    HIP_OK(dev_malloc(&dX, std::max<size_t>(nin * mu, 1) * es));
-    HIP_OK(dev_malloc(&dY, std::max<size_t>(nout * mu, 1) * es));
+    size_t nin = (size_t)D->n_source, nout = (size_t)(whole ? D->n_target : D->row_size);
+    if (trans != 'N') std::swap(nin, nout); // x has one entry per row of the operator, y one per column
+    TempPool tmp;
+    void *dX = tmp.alloc(std::max<size_t>(nin * mu, 1) * es), *dY = tmp.alloc(std::max<size_t>(nout * mu, 1) * es);
     HIP_OK(hipMemcpyAsync(dX, X, nin * mu * es, hipMemcpyHostToDevice, D->stream));
-    device_matmat_device(H, dX, (long long)nin, dY, (long long)nout, mu, host_numbering(H), D->stream);
+    device_matmat_device(H, dX, (long long)nin, dY, (long long)nout, mu, host_numbering(H, trans), D->stream, trans);
     HIP_OK(hipMemcpyAsync(Y, dY, nout * mu * es, hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
-    (void)hipFree(dX);
-    (void)hipFree(dY);
 }
 
 void device_set_phase_timing(const HMatrix &H, bool on) {
@@ -463,7 +573,7 @@ void device_free(DeviceHMatrix *D) {
         if (B.zidxB) (void)hipFree(B.zidxB);
         if (B.tidxA) (void)hipFree(B.tidxA);
     }
-    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16})
+    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16, D->xt})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
                     (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord, (void *)D->tilesB_split, D->ypart})
@@ -490,6 +600,7 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     D->device = S->device; D->tabs = S->tabs; D->is_complex = S->is_complex; D->esize = S->esize;
     D->nB = S->nB; D->nA = S->nA; D->nA2 = S->nA2; D->splitB = S->splitB; D->nB_split = S->nB_split;
     D->one_triangle = S->one_triangle; D->conj_transposed = S->conj_transposed; D->nAT = S->nAT; D->nZ = S->nZ; D->n_zd_tiles = S->n_zd_tiles;
+    D->transposable = S->transposable; D->xt_stride = S->xt_stride;
     D->ycl_stride = S->ycl_stride; D->ypart_stride = S->ypart_stride; D->W_elems = S->W_elems; D->rhs_cap = S->rhs_cap;
     for (int c = 0; c < 4; c++) { D->cntB[c] = S->cntB[c]; D->cntBs[c] = S->cntBs[c]; }
     D->n_source = S->n_source; D->n_target = S->n_target; D->row_off = S->row_off; D->row_size = S->row_size; D->table_bytes = S->table_bytes;
@@ -521,6 +632,7 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     dup_into((void **)&D->zd_woff, S->zd_woff);
     dup_into((void **)&D->zd_rows, S->zd_rows);
     dup_into(&D->ycl, S->ycl);
+    dup_into(&D->xt, S->xt);
     dup_into(&D->W, S->W);
     dup_into((void **)&D->perm_s, S->perm_s);
     dup_into((void **)&D->perm_t, S->perm_t);

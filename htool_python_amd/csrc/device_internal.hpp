@@ -104,6 +104,11 @@ struct DeviceHMatrix {
     int n_zd_tiles = 0;
     void *ycl = nullptr;
     long long ycl_stride = 0;       // elements between the accumulators of consecutive right-hand sides
+    // transposed product of an operator that stores both triangles (tables made on first use, HMatrix::transposable): the tables
+    // above in their "tmode" form, plus x gathered into the cluster numbering of the rows
+    bool transposable = false;
+    void *xt = nullptr;
+    long long xt_stride = 0;
     int cntB[4] = {0, 0, 0, 0}, cntBs[4] = {0, 0, 0, 0}; // tiles per class of the wide kernel (F = 1, 2, 4, 8 columns per wave instruction)
     GTile *tilesB_split = nullptr;
     void *ypart = nullptr;

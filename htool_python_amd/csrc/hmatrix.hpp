@@ -118,6 +118,7 @@ struct HMatrix {
     int col_off = 0, col_size = 0;  // columns covered, cluster numbering
     bool local_numbering = false;   // built as a local block: host products use cluster order on both sides
     bool one_triangle = false;      // symmetric operator stored as its UPLO triangle (off-diagonal leaves are applied twice)
+    bool transposable = false;      // the tables of the transposed product exist (made by the first product with trans = 'T' / 'C')
     bool is_complex = false;
     BuildParams params;
     int tile_max = 128;
@@ -156,10 +157,13 @@ std::string device_name();
 void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems);
 // whole build for a native generator: device ACA + dense evaluation + pack
 void device_build_native(HMatrix &H, const Generator &g);
-void device_matvec_host(const HMatrix &H, const void *x, void *y);                                    // user numbering
-void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream);
-void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream);
-void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y);
+// trans: 'N' y = H x, 'T' y = H^T x, 'C' y = H^H x (x then has one entry per ROW of H, y one per column; "in" / "out" of the
+// numbering refer to x / y).  The tables of the transposed product are made by the first call that asks for it.
+void device_matvec_host(const HMatrix &H, const void *x, void *y, char trans = 'N');                  // user numbering
+void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int numbering, void *stream, char trans = 'N');
+void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream, char trans = 'N');
+void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y, char trans = 'N');
+void device_make_transposable(HMatrix &H);
 int64_t device_recompress(HMatrix &H, double eps);
 void device_clone(const HMatrix &src, HMatrix &dst);
 void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *B);

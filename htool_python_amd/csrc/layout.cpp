@@ -128,10 +128,10 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
         else { b.v_obase = b.tpos; b.v_ostride = 0; }
     }
 
-    // ---- one-triangle storage: slots for the transposed use of every phase-B column.  Per target node the columns
-    // (low-rank first, then dense, in ucol order) get a contiguous block of final slots; nodes spanning several row
+    // ---- one-triangle storage / transposed products: slots for the transposed use of every phase-B column.  Per target node the
+    // columns (low-rank first, then dense, in ucol order) get a contiguous block of final slots; nodes spanning several row
     // tiles also get a [tile][column] panel of partials that is summed after phase B (same scheme as the source side).
-    if (H.one_triangle) {
+    if (H.one_triangle || H.transposable) {
         std::vector<int64_t> zf(nt, -1), zp(nt, -1);
         std::vector<int> zld(nt, 0);
         int64_t cur2 = H.r_elems;
@@ -156,7 +156,7 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
             b.zfin = r_start + zf[b.t_node] + local;
             if (zp[b.t_node] >= 0) { b.z_obase = r_start + zp[b.t_node] + local; b.z_ostride = zld[b.t_node]; }
             else { b.z_obase = b.zfin; b.z_ostride = 0; }
-            if (b.t_off == b.s_off) continue; // diagonal leaf: applied once
+            if (H.one_triangle && b.t_off == b.s_off) continue; // one-triangle storage: a diagonal leaf is applied once
             if (b.rank < 0) // dense: A^T x goes to the y rows of the leaf's source cluster, tile by tile
                 for (int c = H.ctiles.node_tile_begin[b.s_node]; c < H.ctiles.node_tile_end[b.s_node]; c++) {
                     L.zd_tile.push_back(c);

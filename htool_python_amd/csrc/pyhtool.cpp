@@ -268,6 +268,23 @@ struct PyHMatrix {
         check(rc);
         return result;
     }
+    // extension: y = H^T x ('T') or H^H x ('C'), one column or several; x has one entry per row of H
+    py::array_t<T, py::array::f_style> transposed_mul(const py::array_t<T, py::array::f_style> &input, char trans) const {
+        if (input.ndim() != 1 && input.ndim() != 2) throw std::runtime_error("Wrong dimension for transposed HMatrix product");
+        if (input.shape(0) != htool_hmatrix_nb_rows(h)) throw std::runtime_error("Wrong size for transposed HMatrix product");
+        const int mu = input.ndim() == 1 ? 1 : (int)input.shape(1);
+        py::array_t<T, py::array::f_style> result = input.ndim() == 1 ? py::array_t<T, py::array::f_style>(htool_hmatrix_nb_cols(h))
+                                                                        : py::array_t<T, py::array::f_style>({(py::ssize_t)htool_hmatrix_nb_cols(h), (py::ssize_t)mu});
+        std::fill_n(result.mutable_data(), result.size(), T(0));
+        T one(1), zero(0);
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = htool_hmatrix_matmat(h, trans, &one, input.data(), mu, &zero, result.mutable_data());
+        }
+        check(rc);
+        return result;
+    }
     py::array_t<T, py::array::f_style> dense(bool user) const {
         py::array_t<T, py::array::f_style> out({(py::ssize_t)htool_hmatrix_nb_rows(h), (py::ssize_t)htool_hmatrix_nb_cols(h)});
         std::fill_n(out.mutable_data(), out.size(), T(0));
@@ -591,6 +608,11 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("matmat_device", [](const H &s, std::uintptr_t x_dev, long long ldx, std::uintptr_t y_dev, long long ldy, int mu, int numbering, std::uintptr_t stream) {
                 check(htool_hmatrix_matmat_device(s.h, (const void *)x_dev, ldx, (void *)y_dev, ldy, mu, numbering, (void *)stream));
             }, "x_ptr"_a, "ldx"_a, "y_ptr"_a, "ldy"_a, "mu"_a, "numbering"_a = 0, "stream"_a = 0)
+        .def("matmat_device_trans", [](const H &s, char trans, std::uintptr_t x_dev, long long ldx, std::uintptr_t y_dev, long long ldy, int mu, int numbering, std::uintptr_t stream) {
+                check(htool_hmatrix_matmat_device_trans(s.h, trans, (const void *)x_dev, ldx, (void *)y_dev, ldy, mu, numbering, (void *)stream));
+            }, "trans"_a, "x_ptr"_a, "ldx"_a, "y_ptr"_a, "ldy"_a, "mu"_a, "numbering"_a = 0, "stream"_a = 0)
+        .def("transposed_mul", &H::transposed_mul, "x"_a, "trans"_a = 'T',
+             "extension: H^T x (trans='T') or H^H x ('C') for a vector or the columns of a matrix; x has one entry per row of H")
         .def_property_readonly("_handle", [](const H &s) { return (std::uintptr_t)s.h; });
 
     // checkpoint / resume: rebuild an H-matrix from leaves and panels saved by htool_python_amd/io.py

@@ -11,8 +11,17 @@ static void (*g_sink)(int, const char *) = nullptr;
 
 void set_log_sink(void (*sink)(int, const char *)) { g_sink = sink; }
 
+static thread_local DeferredLog *t_deferred = nullptr;
+void defer_log_to(DeferredLog *d) { t_deferred = d; }
+
 void log_message(int level, const std::string &msg) {
+    if (t_deferred) { t_deferred->held.emplace_back(level, msg); return; }
     if (g_sink) g_sink(level, msg.c_str());
+}
+
+void flush_deferred(DeferredLog &d) {
+    for (auto &m : d.held) log_message(m.first, m.second);
+    d.held.clear();
 }
 
 std::string strprintf(const char *fmt, ...) {

@@ -98,16 +98,18 @@ class _HMatrixLocalToLocal(ILocalToLocalOperator):
     local_source_renumbering = property(lambda self: self._s)
 
     def local_add_vector_product(self, trans, alpha, input, beta, output):
-        if trans != "N":
-            raise RuntimeError("H-matrix product: only trans='N' is implemented on the HIP path")
         output *= beta
-        output += alpha * (self.hmatrix * np.ascontiguousarray(input))
+        if trans == "N":
+            output += alpha * (self.hmatrix * np.ascontiguousarray(input))
+        else:  # 'T' / 'C': the transposed sweeps of the same panels (include/htool_mi355x.h: htool_hmatrix_matvec)
+            output += alpha * self.hmatrix.transposed_mul(np.ascontiguousarray(input), trans)
 
     def local_add_matrix_product_row_major(self, trans, alpha, input, beta, output):
-        if trans != "N":
-            raise RuntimeError("H-matrix product: only trans='N' is implemented on the HIP path")
         output *= beta
-        output += alpha * np.asarray(self.hmatrix @ np.asfortranarray(input))
+        if trans == "N":
+            output += alpha * np.asarray(self.hmatrix @ np.asfortranarray(input))
+        else:
+            output += alpha * np.asarray(self.hmatrix.transposed_mul(np.asfortranarray(input), trans))
 
 
 class DistributedOperator:

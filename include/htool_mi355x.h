@@ -163,7 +163,11 @@ const htool_cluster *htool_hmatrix_target_cluster(const htool_hmatrix *h); /* hm
 const htool_cluster *htool_hmatrix_source_cluster(const htool_hmatrix *h); /* hmatrix.hpp:56, borrowed */
 
 /* y = alpha * op(H) x + beta * y, host pointers, USER numbering; replaces
- * htool::add_hmatrix_vector_product (hmatrix.hpp:113).  trans: 'N' only. */
+ * htool::add_hmatrix_vector_product (hmatrix.hpp:113).  trans: 'N' (op(H) = H), 'T' (H^T) or 'C' (H^H; 'T' for a real
+ * operator) -- the value the reference passes through from lu_solve / the local-operator hooks (hmatrix.hpp:64-78).  For
+ * 'T' / 'C' x has one entry per row of H and y one per column.  The first transposed product of an operator makes its extra
+ * index tables (a few per cent of the panels; the panels themselves are used as they are); for one-triangle storage only
+ * the transposition that leaves the operator unchanged is accepted ('T' for symmetry 'S', 'C' for 'H'). */
 int htool_hmatrix_matvec(const htool_hmatrix *h, char trans, const void *alpha, const void *x, const void *beta, void *y);
 /* Y = alpha H X + beta Y, X column-major n_cols x mu; replaces add_hmatrix_matrix_product (hmatrix.hpp:134) */
 int htool_hmatrix_matmat(const htool_hmatrix *h, char trans, const void *alpha, const void *X, int mu, const void *beta, void *Y);
@@ -175,6 +179,9 @@ int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void 
 /* Y = H X on device buffers: mu right-hand sides, column c of X at X_dev + c*ldx elements (same for Y).
  * All columns are multiplied in sweeps of up to 8 right-hand sides per pass over the panels. */
 int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream);
+/* the same with trans as in htool_hmatrix_matvec; for 'T' / 'C' the "in" side of the numbering is the target side (x has
+ * one entry per row of this H-matrix: its local row slice when cluster-numbered), the "out" side the source side */
+int htool_hmatrix_matmat_device_trans(const htool_hmatrix *h, char trans, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream);
 
 /* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
 int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);

@@ -68,9 +68,13 @@ def test_c_abi_end_to_end(built, oracle):
     assert L.htool_hmatrix_set_phase_timing(H, 1) == 0
     assert L.htool_hmatrix_matvec(H, ctypes.c_char(b"N"), None, x.ctypes, None, y2.ctypes) == 0
     assert L.htool_hmatrix_phase_times(H, times) >= 1 and times[3] > 0
-    # errors: transposed products are not implemented; the message is retrievable
-    assert L.htool_hmatrix_matvec(H, ctypes.c_char(b"T"), None, x.ctypes, None, y.ctypes) != 0
-    assert b"trans='N'" in L.htool_last_error()
+    # transposed product (the kernel is symmetric, the compressed operator only up to epsilon)
+    yt = np.zeros(N)
+    assert L.htool_hmatrix_matvec(H, ctypes.c_char(b"T"), None, x.ctypes, None, yt.ctypes) == 0, L.htool_last_error()
+    assert np.linalg.norm(yt - O.dense_matvec(O.K_LAPLACE, points, points, x)) / np.linalg.norm(yt) < 1e-5
+    # errors: the message is retrievable
+    assert L.htool_hmatrix_matvec(H, ctypes.c_char(b"X"), None, x.ctypes, None, y.ctypes) != 0
+    assert b"trans must be" in L.htool_last_error()
     L.htool_hmatrix_destroy(H)
     L.htool_generator_destroy(gen)
     L.htool_cluster_destroy(root)

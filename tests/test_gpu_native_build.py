@@ -190,6 +190,15 @@ def test_full_size_configs_by_properties(built, oracle, n, eps, kind, p0, leaf):
 
     stats = independent_leaf_checks(H, pts, pts, kind, p0, eps, n_sample=200, max_block=500, seed=1)
     assert stats["leaves"] == 200
+    # transposed product at full size (tables made on first use; no row tile is cut in slices at 1 M points): the adjoint
+    # identity  w . (H x) = (H^T w) . x  and sampled exact entries (the kernels are symmetric: row j of A is column j)
+    if not complex_ or n <= 100_000:
+        zt = H.transposed_mul(z, "T")
+        lhs, rhs = np.sum(z * y), np.sum(zt * x)  # (no conjugation: the transpose, not the adjoint)
+        assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+        ze = O.dense_matvec(kind, pts, pts, z, p0, rows=rows)
+        assert np.linalg.norm(zt[rows] - ze) / np.linalg.norm(ze) < eps
+        assert np.array_equal(H * x, y)
     del H
     Htool.release_workspace()
 
