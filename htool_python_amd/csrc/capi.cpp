@@ -343,7 +343,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
     d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size; d.local_numbering = s.local_numbering; d.one_triangle = s.one_triangle;
     d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.ctile_group = s.ctile_group; d.blocks = s.blocks; d.r_elems = s.r_elems;
-    d.build_seconds = s.build_seconds; d.n_batches = s.n_batches;
+    d.build_seconds = s.build_seconds; d.n_batches = s.n_batches; d.transposable = s.transposable;
     c->tch = h->tch; c->sch = h->sch;
     device_clone(s, d);
     *out = c.release();
