@@ -187,6 +187,8 @@ def main():
                          "layout), 'one-triangle' stores the lower triangle only and uses every leaf twice in a fused sweep")
     ap.add_argument("--no-phase-timing", action="store_true", help="do not record the per-phase HIP events (the roofline object is then empty); "
                                                                     "lets the library replay repeated products as a hipGraph")
+    ap.add_argument("--trans", default="N", choices=["N", "T", "C"], help="time the transposed product y = H^T x (H^H x) instead (single GPU; not the headline metric: "
+                                                                          "no per-phase events, the roofline object stays empty)")
     ap.add_argument("--no-warm-build", action="store_true", help="skip the small untimed warm-up build (build_s then includes the one-off costs of a "
                                                                   "process's first build: code objects, streams, first allocations)")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the error against sampled exact rows is always reported)")
@@ -276,6 +278,7 @@ def main():
     else:
         gen = Htool.NativeGenerator(args.kernel, pts, pts, param)
         builder = Htool.HMatrixTreeBuilder(args.eps, args.eta, "S" if args.symmetric else "N", "L" if args.symmetric else "N")
+    assert args.trans == "N" or not dist_mode, "--trans is a single-GPU option (the distributed operator is 'N'-only, as the reference's)"
     if args.symmetric:
         assert not dist_mode, "--symmetric is a single-GPU option (a row partition is not a symmetric operator)"
         builder.set_symmetric_storage(args.symmetric == "one-triangle")
@@ -327,7 +330,9 @@ def main():
             y = torch.zeros(args.rhs, n, dtype=dtype, device="cuda")
 
         def step():
-            if args.rhs > 1:
+            if args.trans != "N":
+                H.matmat_device_trans(args.trans, x.data_ptr(), n, y.data_ptr(), n, args.rhs, 0, stream)
+            elif args.rhs > 1:
                 H.matmat_device(x.data_ptr(), n, y.data_ptr(), n, args.rhs, 0, stream)
             else:
                 H.matvec_device(x.data_ptr(), y.data_ptr(), 0, stream)
@@ -424,7 +429,10 @@ def main():
             xx, yy = x.cpu().numpy(), y.cpu().numpy()
             if args.rhs > 1:
                 xx, yy = xx[0], yy[0]
-            ye = O.dense_matvec(kind, pts, pts, xx, param, rows=rows)
+            if args.trans == "C":  # the kernels are symmetric (A^T = A): A^H x = conj(A conj(x))
+                ye = np.conj(O.dense_matvec(kind, pts, pts, np.conj(xx), param, rows=rows))
+            else:
+                ye = O.dense_matvec(kind, pts, pts, xx, param, rows=rows)
             rel_err = float(np.linalg.norm(yy[rows] - ye) / np.linalg.norm(ye))
         else:
             # every rank checks rows of its own partition against the exact operator applied to the gathered x
@@ -482,6 +490,7 @@ def main():
         "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,
         "rhs_per_step": args.rhs,
+        "trans": args.trans,
         "symmetric_storage": args.symmetric,
         "per_rank": per_rank,   # multi-GPU: bytes, product time (sum of its kernels, HIP events) and exchange time of every rank
         "rel_err_sampled_rows": rel_err,

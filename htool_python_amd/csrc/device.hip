@@ -260,13 +260,13 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     D->rhs_cap = nr;
 }
 
-// ---- sixteen right-hand sides per sweep on the matrix cores (real operators, both triangles stored) ----
+// ---- sixteen right-hand sides per sweep on the matrix cores (operators that store both triangles) ----
 static void ensure_w16(DeviceHMatrix *D) {
     if (D->W16) return;
     drop_product_graph(D);
     void *w = nullptr;
-    HIP_OK(dev_malloc(&w, (size_t)D->W_elems * 16 * sizeof(double)));
-    HIP_OK(hipMemset(w, 0, (size_t)D->W_elems * 16 * sizeof(double)));
+    HIP_OK(dev_malloc(&w, (size_t)D->W_elems * 16 * D->esize));
+    HIP_OK(hipMemset(w, 0, (size_t)D->W_elems * 16 * D->esize));
     // the partial sums phase A2 reduces, as index ranges of the coefficient workspace (read back from the A2 tables)
     std::vector<Reduce16> items;
     if (D->nA2) {
@@ -276,7 +276,7 @@ static void ensure_w16(DeviceHMatrix *D) {
             GSeg sg;
             HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
             Reduce16 r;
-            r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)sizeof(double);
+            r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)D->esize;
             r.out_base = x.out_begin;
             r.ld = sg.ld_last; r.nrows = sg.nrows_t; r.ncols = sg.ncols;
             for (r.row0 = 0; r.row0 < r.nrows; r.row0 += 16) items.push_back(r); // one work item per 16 rows
@@ -287,20 +287,22 @@ static void ensure_w16(DeviceHMatrix *D) {
     D->W16 = w;
 }
 
-static void launch_sweep16(DeviceHMatrix *D, const double *x, long long x_stride, double *y, long long y_stride, int nr, int numbering, hipStream_t st) {
-    double *W16 = (double *)D->W16;
+template <typename T>
+static void launch_sweep16(DeviceHMatrix *D, const T *x, long long x_stride, T *y, long long y_stride, int nr, int numbering, hipStream_t st) {
+    constexpr bool CPLX = sizeof(T) == 16;
+    T *W16 = (T *)D->W16;
     const int Ns = D->n_source;
     const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
     hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
     const bool timing = D->phase_timing;
     if (timing) HIP_OK(hipEventRecord(ev[0], st));
-    if (Ns) hipLaunchKernelGGL(gather_x16_kernel, dim3((unsigned)((Ns + 63) / 64)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_s : (const int *)nullptr, W16, Ns, nr);
+    if (Ns) hipLaunchKernelGGL(gather_x16_kernel<T>, dim3((unsigned)((Ns + 63) / 64)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_s : (const int *)nullptr, W16, Ns, nr);
     if (timing) HIP_OK(hipEventRecord(ev[1], st));
-    if (D->nA) hipLaunchKernelGGL(tile_gemm_tall16, dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, W16);
+    if (D->nA) hipLaunchKernelGGL(tile_gemm_tall16<CPLX>, dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (double *)W16);
     if (timing) HIP_OK(hipEventRecord(ev[2], st));
-    if (D->n_red16) hipLaunchKernelGGL(reduce_partials16_kernel, dim3(D->n_red16), dim3(256), 0, st, (const Reduce16 *)D->red16, W16);
+    if (D->n_red16) hipLaunchKernelGGL(reduce_partials16_kernel<T>, dim3(D->n_red16), dim3(256), 0, st, (const Reduce16 *)D->red16, W16);
     if (timing) HIP_OK(hipEventRecord(ev[3], st));
-    if (D->nB) hipLaunchKernelGGL(tile_gemm_wide16, dim3(D->nB), dim3(256), 0, st, out_user ? D->tilesB_user : D->tilesB_cluster, D->segs, (const double *)W16, y, y_stride, nr);
+    if (D->nB) hipLaunchKernelGGL(tile_gemm_wide16<CPLX>, dim3(D->nB), dim3(256), 0, st, out_user ? D->tilesB_user : D->tilesB_cluster, D->segs, (const double *)W16, (double *)y, y_stride, nr);
     if (timing) HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
     if (timing) D->nprod++;
@@ -325,13 +327,12 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
             else { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; }
             continue;
         }
-        if constexpr (std::is_same<Ops, RealOps>::value) {
-            if (left > 8 && D->W16) { // one sweep of the panels for up to 16 right-hand sides, on the matrix cores
-                const int nr = std::min(left, 16);
-                launch_sweep16(D, (const double *)x, x_stride, (double *)y, y_stride, nr, numbering, st);
-                done += nr;
-                continue;
-            }
+        // more than 8 columns left: one sweep of the panels for up to 16 right-hand sides, on the matrix cores
+        if (left > 8 && D->W16) {
+            const int nr = std::min(left, 16);
+            launch_sweep16<T>(D, x, x_stride, y, y_stride, nr, numbering, st);
+            done += nr;
+            continue;
         }
         if (left >= 8) { launch_sweep<Ops, 8>(D, x, x_stride, y, y_stride, numbering, st); done += 8; }
         else if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
@@ -419,7 +420,7 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
         return;
     }
     const int need = D->one_triangle ? (mu >= 4 ? 4 : mu >= 2 ? 2 : 1) : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
-    if (mu > 8 && !D->is_complex && !D->one_triangle && !D->W16 && mfma_sweep_enabled()) {
+    if (mu > 8 && !D->one_triangle && !D->W16 && mfma_sweep_enabled()) {
         HIP_OK(hipStreamSynchronize(st));
         ensure_w16(D);
     }

@@ -189,8 +189,8 @@ def test_custom_dense_blocks_generator(built, oracle):
 @pytest.mark.parametrize("complex_", [False, True])
 def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
     """H @ X (src/htool/hmatrix/hmatrix.hpp:119-138) multiplies up to 8 right-hand sides per VALU sweep of the panels --
-    every column then equals the single-vector product bit for bit (same summation order) -- and, for real operators with
-    more than 8 columns, 16 per sweep on the matrix cores (v_mfma_f64_16x16x4_f64: other summation order, <= 1e-13)."""
+    every column then equals the single-vector product bit for bit (same summation order) -- and, with more than 8 columns,
+    16 per sweep on the matrix cores (v_mfma_f64_16x16x4_f64, real and complex: other summation order, <= 1e-13)."""
     import Htool
     from tests.helpers import cluster_of
 
@@ -208,7 +208,7 @@ def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
         X = np.asfortranarray(X)
         Y = H @ X
         assert Y.shape == (n, mu) and Y.flags.f_contiguous
-        mfma = mu > 8 and not complex_
+        mfma = mu > 8
         for c in range(mu):
             yc = H * np.ascontiguousarray(X[:, c])
             if mfma and c < (mu // 16) * 16 + (16 if mu % 16 > 8 else 0):
@@ -218,7 +218,7 @@ def test_multi_rhs_sweep_equals_column_products(built, oracle, complex_):
         if mfma:
             assert np.array_equal(Y, H @ X)  # bitwise repeatable
             # a column's result does not depend on its neighbours or on their number
-            X2 = np.asfortranarray(np.random.rand(n, 12))
+            X2 = np.asfortranarray(np.random.rand(n, 12) + (1j * np.random.rand(n, 12) if complex_ else 0))
             X2[:, 3] = X[:, 3]
             assert np.array_equal((H @ X2)[:, 3], Y[:, 3])
     Ye = O.dense_matvec(O.K_HELMHOLTZ if complex_ else O.K_LAPLACE, pts, pts, X, 6.0 if complex_ else 0.0)
@@ -286,6 +286,60 @@ def test_sixteen_wide_mfma_sweep(built, oracle, case):
         assert np.array_equal(Yd.cpu().numpy().T, Y)
         rows = perm[sub.get_offset():sub.get_offset() + sub.get_size()]
         Ye = O.dense_matvec(O.K_LAPLACE, T, S, X, rows=rows)
+        assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["leaf10", "leaf40", "leaf100", "rect", "partition"])
+def test_sixteen_wide_mfma_sweep_complex(built, oracle, case, monkeypatch):
+    """The same for complex128 operators (Helmholtz): a 16-byte load is one (re, im) row, four MFMAs per load into a real and
+    an imaginary accumulator tile.  Row tiles of <= 16, <= 32 and <= 64 rows, rectangular, one partition; against the
+    single-vector products (1e-13), the 8-wide VALU sweeps and the exact dense operator."""
+    import torch
+
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    np.random.seed(5)
+    rng = np.random.RandomState(5)
+    leaf = {"leaf10": 10, "leaf40": 40}.get(case, 100)
+    n = 5000 if leaf == 100 else 2500
+    T = O.points_in_sphere(n)
+    S = O.points_in_sphere(2100) + np.array([[0.4], [0.0], [0.0]]) if case == "rect" else T
+    world = 3 if case == "partition" else 1
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    tcl = b.create_cluster_tree(T, 2, size_of_partition=world)
+    scl = tcl if S is T else cluster_of(S, leaf)
+    gen = Htool.ComplexNativeGenerator("helmholtz", T, S, 6.0)
+    H = Htool.ComplexHMatrixTreeBuilder(1e-5, 10.0, "N", "N").build(gen, tcl, scl, 1 if case == "partition" else -1)
+    ns = S.shape[1]
+    for mu in (9, 16, 21):
+        X = np.asfortranarray(rng.random_sample((ns, mu)) + 1j * rng.random_sample((ns, mu)))
+        Y = np.asarray(H @ X)
+        assert np.array_equal(Y, np.asarray(H @ X))  # fixed summation order
+        for c in range(mu):
+            yc = H * np.ascontiguousarray(X[:, c])
+            assert np.linalg.norm(Y[:, c] - yc) <= 1e-13 * np.linalg.norm(yc), (case, mu, c)
+        if case != "partition":
+            Ye = O.dense_matvec(O.K_HELMHOLTZ, T, S, X, 6.0)
+            assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-5
+    # the VALU sweeps (8 columns at a time) give the same columns
+    monkeypatch.setenv("HTOOL_MULTI_RHS_KERNEL", "valu")
+    H2 = Htool.ComplexHMatrixTreeBuilder(1e-5, 10.0, "N", "N").build(gen, tcl, scl, 1 if case == "partition" else -1)
+    Yv = np.asarray(H2 @ X)
+    assert np.linalg.norm(Yv - Y) <= 1e-13 * np.linalg.norm(Y)
+    monkeypatch.delenv("HTOOL_MULTI_RHS_KERNEL")
+    if case == "partition":  # the multi-GPU path: cluster-numbered x in, the local row slice out, on device buffers
+        sub = tcl.get_cluster_on_partition(1)
+        perm = np.asarray(tcl.get_permutation())
+        Xd = torch.from_numpy(np.ascontiguousarray(X[perm].T)).cuda()  # mu x n, cluster numbering
+        Yd = torch.zeros(mu, sub.get_size(), dtype=torch.complex128, device="cuda")
+        H.matmat_device(Xd.data_ptr(), ns, Yd.data_ptr(), sub.get_size(), mu, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(Yd.cpu().numpy().T, Y)
+        rows = perm[sub.get_offset():sub.get_offset() + sub.get_size()]
+        Ye = O.dense_matvec(O.K_HELMHOLTZ, T, S, X, 6.0, rows=rows)
         assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < 1e-5
 
 
