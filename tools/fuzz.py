@@ -112,6 +112,23 @@ def main(budget, seed, only_case=None, with_oracle=False):
             Y = H @ X
             y_ref = y if part == 1 else y[local_users]
             ok = ok and np.allclose(Y[:, 0], y_ref, rtol=1e-11, atol=1e-13 * scale) and np.allclose(Y[:, 1], -y_ref, rtol=1e-11, atol=1e-13 * scale)
+            # more than 8 columns: the 16-wide sweep on the matrix cores (operators that store both triangles), real and complex
+            X16 = np.asfortranarray(np.stack([x * (1.0 + 0.1 * c) for c in range(11)], axis=1))
+            Y16 = H @ X16
+            ok = ok and np.allclose(Y16[:, 0], y_ref, rtol=1e-10, atol=1e-12 * scale) and np.allclose(Y16[:, 10], 2.0 * y_ref, rtol=1e-10, atol=1e-12 * scale)
+            # transposed product (tables made on first use; one-triangle storage answers with the stored operator) against exact
+            # entries -- the kernels are functions of the distance, so (A^T w)[j] = sum_i K(s_j, t_i) w_i
+            t_pts = pt if part == 1 else np.asfortranarray(pt[:, local_users])
+            w = pick_rng.rand(t_pts.shape[1]) + (1j * pick_rng.rand(t_pts.shape[1]) if cplx else 0)
+            cols = pick_rng.choice(ns, min(ns, 48), replace=False)
+            z = H.transposed_mul(w, "T")
+            ze = exact_rows(kind, ps, t_pts, w, p0, cols)
+            zscale = np.linalg.norm(ze) + 1e-300
+            errT = np.linalg.norm(z[cols] - ze) / zscale
+            ok = ok and z.shape == (ns,) and np.all(np.isfinite(z)) and errT < tol
+            ok = ok and np.array_equal(H * x, y_ref)  # the direct product after the tables were written again
+            lhs, rhs = np.sum(w * y_ref), np.sum(z * x)
+            ok = ok and abs(lhs - rhs) <= 1e-9 * (abs(lhs) + np.linalg.norm(w) * np.linalg.norm(y_ref) * 1e-3)
             if recompress:
                 H2 = copy.deepcopy(H)
                 Htool.recompression(H2, max(eps * 10, 1e-6))
@@ -131,7 +148,7 @@ def main(budget, seed, only_case=None, with_oracle=False):
                 OH = O.HMatrix(oc, ocs, {"inv_delta": 0, "laplace": 1, "helmholtz": 2}[kind], p0, is_complex=cplx, eps=eps, eta=eta, symmetry=sym, uplo=uplo)
                 yo = OH.matvec(x)
                 print(f"   oracle: err {np.linalg.norm(yo[rows] - ye) / scale:.2e}, |y - y_oracle|/|y| {np.linalg.norm(y - yo) / np.linalg.norm(yo):.2e}", flush=True)
-            print(("ok  " if ok else "FAIL"), f"{time.time() - t0:6.2f}s err {err:.2e}", label, flush=True)
+            print(("ok  " if ok else "FAIL"), f"{time.time() - t0:6.2f}s err {err:.2e} errT {errT:.2e}", label, flush=True)
             if not ok:
                 n_fail += 1
         except Exception as e:  # noqa: BLE001
