@@ -250,7 +250,24 @@ def main():
 
     logging.getLogger("Htool").addHandler(_Keep())
     logging.getLogger("Htool").setLevel(logging.INFO)
+    vram_prep = None
     if not args.no_warm_build:
+        # Device memory is handed out by the driver wiped: the first allocation of a VRAM region costs ~27 ms per GB, and memory freed
+        # by this or by the previous process is wiped in the background (~45 ms per GB) while new allocations wait for it
+        # (tools/vram_first_touch.py on a fresh box: 100 GB in 2.7 s, again 1 s after the free 4.5 s, again 6 s later 1 ms).  A build
+        # allocates ~170 GB at once, so build_s would swing between 0.4 and 4.8 s with what ran on the GPU before.  Untimed, like
+        # the warm-up products: touch the memory once, give it back, and let the wipe finish.
+        if not (dist_mode and args.backend == "gloo"):  # (rehearsal ranks share a GPU: nothing to grab)
+            free_b, _total_b = torch.cuda.mem_get_info()
+            t_prep = time.time()
+            touch = torch.empty(int(free_b * 0.8), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            t_alloc = time.time() - t_prep
+            del touch
+            torch.cuda.empty_cache()
+            wait_s = 1.0 + 0.05 * free_b * 0.8 / 1e9
+            time.sleep(wait_s)
+            vram_prep = {"touched_GB": free_b * 0.8 / 1e9, "alloc_s": t_alloc, "wait_s": wait_s}
         # untimed warm-up, as for the products: a 20 000-point operator of the same kernel and dtype takes the one-off costs of a
         # process's first build (code objects of the build kernels, streams, the first allocations) out of build_s
         wp = points_in_sphere(20000, seed=1)
@@ -485,6 +502,7 @@ def main():
         },
         "build_s": t_build,
         "build_warmed": not args.no_warm_build,
+        "vram_preconditioning": vram_prep,
         "build_breakdown": build_log[-1] if build_log else None,
         "recompression_s": t_recompress,
         "cluster_tree_s": t_cluster,
