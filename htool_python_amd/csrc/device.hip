@@ -22,6 +22,7 @@
 #include "device_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <exception>
 #include <mutex>

@@ -135,7 +135,14 @@ struct DeviceHMatrix {
     double *tcoord = nullptr, *scoord = nullptr;
 };
 
-// per-block device descriptor used by the pack / unpack / ACA kernels
+// what the ACA kernels need of an admissible leaf (40 bytes: the queue of a 1 M-point build is 31 MB to upload instead of 86)
+struct AcaBlock {
+    long long tmp_u, tmp_v; // arena offsets (elements) of the U / V workspace of the leaf
+    int t_off, m, s_off, n;
+    int cap, pad_;
+};
+
+// per-block device descriptor used by the pack / unpack kernels
 struct DevBlock {
     long long tmp_u, tmp_v; // arena offsets (elements)
     long long tpos;

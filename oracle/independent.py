@@ -172,3 +172,78 @@ def leaf_quality(A, U, V, eps):
     """(relative Frobenius error of U V against A, rank, SVD rank at eps / 10)."""
     err = np.linalg.norm(A - U @ V) / max(np.linalg.norm(A), 1e-300)
     return float(err), U.shape[1], svd_rank(A, eps / 10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# block tree (SURVEY.md A.3), verified from its definition WITHOUT running the top-down visit the engine and the C++
+# oracle both implement: a leaf list is right iff (1) every leaf is a pair of cluster nodes, (2) the leaves tile the
+# matrix exactly, (3) every leaf is a place where the visit stops (admissible at sufficient depth -> low rank; two cluster
+# leaves -> dense) and (4) every leaf is REACHABLE: walking UP, there is a chain of pairs from it to the root pair in which
+# every pair is one where the visit does not stop and whose split rule produces the next pair of the chain.
+# ---------------------------------------------------------------------------------------------------------------------
+def check_block_tree(adm, dns, target_nodes, source_nodes, eta, t_root=0, s_root=0, min_target_depth=0, min_source_depth=0, paint_limit=4000):
+    """adm, dns: (k, 4) arrays of (t_off, m, s_off, n); target_nodes / source_nodes: (ints7, dbl4) node tables as in
+    check_cluster_tree.  Returns (#admissible leaves checked, #dense leaves checked)."""
+    ti, td = (np.asarray(a) for a in target_nodes)
+    si, sd = (np.asarray(a) for a in source_nodes)
+    adm, dns = np.asarray(adm).reshape(-1, 4), np.asarray(dns).reshape(-1, 4)
+    t_of = {(int(r[0]), int(r[1])): k for k, r in enumerate(ti)}
+    s_of = {(int(r[0]), int(r[1])): k for k, r in enumerate(si)}
+
+    def admissible(t, s):
+        rt, rs = td[t, 3], sd[s, 3]
+        dist = float(np.linalg.norm(td[t, :3] - sd[s, :3]))
+        return 2.0 * min(rt, rs) < eta * max(0.0, dist - rt - rs)
+
+    def stops(t, s):  # 1: low-rank leaf, 2: dense leaf, 0: the visit goes on
+        if admissible(t, s) and ti[t, 2] >= min_target_depth and si[s, 2] >= min_source_depth:
+            return 1
+        if ti[t, 5] == 0 and si[s, 5] == 0:
+            return 2
+        return 0
+
+    def rule(t, s):  # which side(s) a pair that does not stop is split on
+        t_leaf, s_leaf = ti[t, 5] == 0, si[s, 5] == 0
+        if s_leaf or (not t_leaf and ti[t, 1] > si[s, 1]):
+            return "t"
+        if t_leaf or si[s, 1] > ti[t, 1]:
+            return "s"
+        return "ts"
+
+    memo = {(t_root, s_root): True}
+
+    def reachable(t, s):
+        key = (t, s)
+        if key in memo:
+            return memo[key]
+        memo[key] = False  # (no cycles: every candidate is strictly higher in one of the trees)
+        pt, ps = int(ti[t, 3]), int(si[s, 3])
+        cands = []
+        if t != t_root and pt >= 0:
+            cands.append((pt, s, "t"))
+        if s != s_root and ps >= 0:
+            cands.append((t, ps, "s"))
+        if t != t_root and s != s_root and pt >= 0 and ps >= 0:
+            cands.append((pt, ps, "ts"))
+        ok = any(stops(a, b) == 0 and rule(a, b) == how and reachable(a, b) for a, b, how in cands)
+        memo[key] = ok
+        return ok
+
+    rows0, nrows = int(ti[t_root, 0]), int(ti[t_root, 1])
+    cols0, ncols = int(si[s_root, 0]), int(si[s_root, 1])
+    area = 0
+    paint = np.zeros((nrows, ncols), dtype=np.uint8) if nrows * ncols <= paint_limit * paint_limit else None
+    for kind, leaves in ((1, adm), (2, dns)):
+        for t_off, m, s_off, n in leaves:
+            t, s = t_of.get((int(t_off), int(m))), s_of.get((int(s_off), int(n)))
+            assert t is not None and s is not None, f"leaf ({t_off},{m},{s_off},{n}) is not a pair of cluster nodes"
+            assert stops(t, s) == kind, f"leaf ({t_off},{m},{s_off},{n}): the visit does not stop here as a {'low-rank' if kind == 1 else 'dense'} leaf"
+            assert reachable(t, s), f"leaf ({t_off},{m},{s_off},{n}) is not reached by the visit from the root pair"
+            assert rows0 <= t_off and t_off + m <= rows0 + nrows and cols0 <= s_off and s_off + n <= cols0 + ncols
+            area += int(m) * int(n)
+            if paint is not None:
+                paint[t_off - rows0:t_off - rows0 + m, s_off - cols0:s_off - cols0 + n] += 1
+    assert area == nrows * ncols, "the leaves do not cover the matrix exactly once (area)"
+    if paint is not None:
+        assert paint.min() == 1 and paint.max() == 1, "the leaves overlap or leave a gap"
+    return len(adm), len(dns)

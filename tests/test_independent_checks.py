@@ -120,3 +120,62 @@ def test_explicit_residual_aca_rejects_and_handles_null_rows():
     U, V = I.aca_full_residual(A, 1e-10, transpose_role=True)
     assert U.shape == (40, 1) and np.linalg.norm(A - U @ V) <= 1e-14 * np.linalg.norm(A)
     assert I.svd_rank(A, 1e-10) == 1
+
+
+@pytest.mark.parametrize("eta,leaf,children,world,min_depths", [(10.0, 10, 2, 1, (0, 0)), (3.0, 20, 2, 3, (0, 0)), (0.7, 12, 3, 1, (0, 0)),
+                                                               (100.0, 10, 4, 4, (0, 0)), (10.0, 10, 2, 1, (4, 0)), (10.0, 16, 2, 2, (0, 5))])
+def test_block_tree_from_its_definition(built, oracle, eta, leaf, children, world, min_depths):
+    """The two work queues of the block tree (replaces the recursive pointer tree of
+    htool::HMatrixTreeBuilder::build, hmatrix_tree_builder.hpp:36) verified WITHOUT a top-down visit: every leaf is a pair of
+    cluster nodes where the visit stops, is reachable from the root pair by walking up through pairs whose split rule produces
+    it, and the leaves tile the (row partition x all columns) exactly.  Square and rectangular, every rank's rows of a
+    partition, minimal depths; for the product's queues AND the C++ oracle's."""
+    import Htool
+
+    T, S = _cloud(3, 1800, 3), _cloud(3, 1100, 4)
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(leaf)
+    tcl = b.create_cluster_tree(T, children, size_of_partition=world)
+    for scl, spts in ((tcl, T), (b.create_cluster_tree(S, children, size_of_partition=1), S)):
+        tn, sn = tcl._nodes(), scl._nodes()
+        for p in range(world):
+            t_root = 0 if world == 1 else tcl.get_cluster_on_partition(p)._node_id()
+            adm, dns = Htool.block_tree_queues(tcl, scl, eta, min_target_depth=min_depths[0], min_source_depth=min_depths[1],
+                                               target_partition_number=p if world > 1 else -1)
+            na, nd = I.check_block_tree(adm, dns, tn, sn, eta, t_root=t_root, min_target_depth=min_depths[0], min_source_depth=min_depths[1])
+            assert nd > 0 and (na > 0 or eta < 1.0)
+    # the oracle's block tree through the same check
+    if True:
+        oc = oracle.Cluster(T, n_children=children, size_of_partition=world, max_leaf=leaf)
+        for p in range(world):
+            oadm, odns = oracle.blocktree(oc, oc, eta, min_t=min_depths[0], min_s=min_depths[1], target_partition=p if world > 1 else -1)
+            quad = lambda pairs: np.array([(oc.inodes[t, 0], oc.inodes[t, 1], oc.inodes[s, 0], oc.inodes[s, 1]) for t, s in pairs]).reshape(-1, 4)  # noqa: E731
+            t_root = 0 if world == 1 else int(np.flatnonzero((oc.inodes[:, 2] == 1) & (oc.inodes[:, 6] == p))[0])
+            I.check_block_tree(quad(oadm), quad(odns), (oc.inodes, oc.dnodes), (oc.inodes, oc.dnodes), eta, t_root=t_root,
+                               min_target_depth=min_depths[0], min_source_depth=min_depths[1])
+
+
+def test_block_tree_check_sees_a_wrong_leaf(built):
+    """The check is not vacuous: a leaf list with one admissible block split further, or one block replaced by its parent, fails."""
+    import Htool
+
+    T = _cloud(3, 900, 5)
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(10)
+    cl = b.create_cluster_tree(T, 2)
+    nodes = cl._nodes()
+    adm, dns = (np.asarray(a).copy() for a in Htool.block_tree_queues(cl, cl, 10.0))
+    I.check_block_tree(adm, dns, nodes, nodes, 10.0)
+    ints = np.asarray(nodes[0])
+    of = {(int(r[0]), int(r[1])): k for k, r in enumerate(ints)}
+    # split the largest admissible block on its target side: still a tiling by node pairs, but not where the visit stops / reaches
+    k = int(np.argmax(adm[:, 1] * adm[:, 3]))
+    t = of[(int(adm[k, 0]), int(adm[k, 1]))]
+    assert ints[t, 5] > 0
+    kids = [ints[ints[t, 4] + c] for c in range(ints[t, 5])]
+    bad = np.vstack([np.delete(adm, k, axis=0)] + [np.array([[c[0], c[1], adm[k, 2], adm[k, 3]]]) for c in kids])
+    with pytest.raises(AssertionError):
+        I.check_block_tree(bad, dns, nodes, nodes, 10.0)
+    # with a wrong eta the admissible leaves are no stopping places (or dense ones should have been)
+    with pytest.raises(AssertionError):
+        I.check_block_tree(adm, dns, nodes, nodes, 2.0)
