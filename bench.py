@@ -265,7 +265,7 @@ def main():
             t_alloc = time.time() - t_prep
             del touch
             torch.cuda.empty_cache()
-            wait_s = 1.0 + 0.05 * free_b * 0.8 / 1e9
+            wait_s = 1.0 + 0.06 * free_b * 0.8 / 1e9
             time.sleep(wait_s)
             vram_prep = {"touched_GB": free_b * 0.8 / 1e9, "alloc_s": t_alloc, "wait_s": wait_s}
         # untimed warm-up, as for the products: a 20 000-point operator of the same kernel and dtype takes the one-off costs of a
