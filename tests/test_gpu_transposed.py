@@ -188,3 +188,36 @@ def test_local_operator_hook_with_trans(built, oracle):
     out2 = np.zeros((500, 3))
     op.local_add_matrix_product_row_major("T", 1.0, X, 0.0, out2)
     assert _rel(out2, D.T @ X) < 1e-12
+
+
+def test_transposed_product_after_recompression_and_after_reload(built, oracle, tmp_path, monkeypatch):
+    """The tables of the transposed product are made from the batches as they are NOW: after a recompression in several chunks
+    (every chunk becomes a batch of its own) and for an operator loaded from a checkpoint (one batch, no generator)."""
+    import Htool
+    from htool_python_amd.workloads import points_in_sphere
+    from tests.helpers import cluster_of
+
+    monkeypatch.setenv("HTOOL_RECOMPRESS_ARENA_MB", "20")
+    P = points_in_sphere(12000, seed=9)
+    cl = cluster_of(P, 40)
+    H = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", P, P), cl, cl)
+    rng = np.random.RandomState(1)
+    w, x = rng.random_sample(12000), rng.random_sample(12000)
+    z0 = H.transposed_mul(w)                      # tables exist BEFORE the recompression, too
+    assert Htool.recompression(H, 1e-4) > 0
+    z1 = H.transposed_mul(w)
+    y1 = H * x
+    assert _rel(z1, z0) < 1e-3 and not np.array_equal(z1, z0)
+    assert abs(w @ y1 - z1 @ x) < 1e-10 * abs(w @ y1)
+    # the other order: recompressed first (chunks -> several batches), the tables made afterwards
+    Hb = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", P, P), cl, cl)
+    assert Htool.recompression(Hb, 1e-4) > 0
+    assert _rel(Hb.transposed_mul(w), z1) < 1e-12 and _rel(Hb * x, y1) < 1e-12
+    del Hb
+    path = str(tmp_path / "h.npz")
+    Htool.save_hmatrix(path, H)
+    H2 = Htool.load_hmatrix(path, cl)
+    assert _rel(H2 * x, y1) < 1e-12
+    z2 = H2.transposed_mul(w)
+    assert _rel(z2, z1) < 1e-12
+    assert abs(w @ (H2 * x) - z2 @ x) < 1e-10 * abs(w @ y1)
