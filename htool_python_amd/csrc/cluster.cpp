@@ -30,18 +30,40 @@ struct Geometry {
     double radius;
 };
 
-Geometry compute_geometry(const ClusterTree &T, const double *radii, const double *weights, int off, int sz) {
+// Sums over the points of a node (weighted mean, covariance) are formed in BLOCKS of SUM_BLOCK consecutive points of the
+// cluster order: every block is summed from zero, the block sums are added in block order.  A node of at most SUM_BLOCK points
+// is one block, i.e. the plain running sum; the large nodes at the top of the tree -- where a level has fewer nodes than threads
+// and these passes used to run on one thread -- have their blocks summed by all threads, with the same result whatever their number.
+constexpr int SUM_BLOCK = 4096;
+
+Geometry compute_geometry(const ClusterTree &T, const double *radii, const double *weights, int off, int sz, bool parallel = false) {
     const int d = T.dim;
     Geometry g{{0, 0, 0}, 0};
+    const int nb = (sz + SUM_BLOCK - 1) / SUM_BLOCK;
+    std::vector<double> part((size_t)std::max(nb, 1) * 4, 0.0); // per block: sum w x, sum w y, sum w z, sum w
+    const bool par = parallel && nb > 1;
+#pragma omp parallel for schedule(static) if (par)
+    for (int b = 0; b < nb; b++) {
+        double c[3] = {0, 0, 0}, wsum = 0;
+        const int i1 = std::min(sz, (b + 1) * SUM_BLOCK);
+        for (int i = b * SUM_BLOCK; i < i1; i++) {
+            int u = T.perm[off + i];
+            double w = weights ? weights[u] : 1.0;
+            wsum += w;
+            for (int k = 0; k < d; k++) c[k] += w * T.coords[(size_t)u * d + k];
+        }
+        for (int k = 0; k < 3; k++) part[(size_t)b * 4 + k] = c[k];
+        part[(size_t)b * 4 + 3] = wsum;
+    }
     double wsum = 0;
-    for (int i = 0; i < sz; i++) {
-        int u = T.perm[off + i];
-        double w = weights ? weights[u] : 1.0;
-        wsum += w;
-        for (int k = 0; k < d; k++) g.c[k] += w * T.coords[(size_t)u * d + k];
+    for (int b = 0; b < nb; b++) {
+        for (int k = 0; k < d; k++) g.c[k] += part[(size_t)b * 4 + k];
+        wsum += part[(size_t)b * 4 + 3];
     }
     if (wsum != 0)
         for (int k = 0; k < d; k++) g.c[k] /= wsum;
+    double radius = 0; // (a maximum: the same in any order)
+#pragma omp parallel for schedule(static) reduction(max : radius) if (par)
     for (int i = 0; i < sz; i++) {
         int u = T.perm[off + i];
         double s = 0;
@@ -50,8 +72,9 @@ Geometry compute_geometry(const ClusterTree &T, const double *radii, const doubl
             s += t * t;
         }
         double r = std::sqrt(s) + (radii ? radii[u] : 0.0);
-        if (r > g.radius) g.radius = r;
+        if (r > radius) radius = r;
     }
+    g.radius = radius;
     return g;
 }
 
@@ -107,25 +130,40 @@ std::vector<int> split_range(ClusterTree &T, const double *weights, int off, int
     const bool pca = strategy == 0 || strategy == 1, regular = strategy == 0 || strategy == 2;
     if (pca) {
         double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (int i = 0; i < sz; i++) {
-            int u = T.perm[off + i];
-            double w = weights ? weights[u] : 1.0, t[3];
-            for (int k = 0; k < d; k++) t[k] = T.coords[(size_t)u * d + k] - centre[k];
-            for (int p = 0; p < d; p++)
-                for (int q = 0; q < d; q++) cov[p][q] += w * t[p] * t[q];
+        const int nb = (sz + SUM_BLOCK - 1) / SUM_BLOCK; // blocked sums, see compute_geometry
+        std::vector<double> part((size_t)std::max(nb, 1) * 9, 0.0);
+        const bool par_sum = parallel_sort && nb > 1;
+#pragma omp parallel for schedule(static) if (par_sum)
+        for (int b = 0; b < nb; b++) {
+            double cb[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            const int i1 = std::min(sz, (b + 1) * SUM_BLOCK);
+            for (int i = b * SUM_BLOCK; i < i1; i++) {
+                int u = T.perm[off + i];
+                double w = weights ? weights[u] : 1.0, t[3];
+                for (int k = 0; k < d; k++) t[k] = T.coords[(size_t)u * d + k] - centre[k];
+                for (int p = 0; p < d; p++)
+                    for (int q = 0; q < d; q++) cb[p][q] += w * t[p] * t[q];
+            }
+            for (int p = 0; p < 3; p++)
+                for (int q = 0; q < 3; q++) part[(size_t)b * 9 + p * 3 + q] = cb[p][q];
         }
+        for (int b = 0; b < nb; b++)
+            for (int p = 0; p < d; p++)
+                for (int q = 0; q < d; q++) cov[p][q] += part[(size_t)b * 9 + p * 3 + q];
         dominant_axis(cov, d, dir);
     } else {
         double lo[3], hi[3];
-        for (int k = 0; k < d; k++) lo[k] = 1e300, hi[k] = -1e300;
+        for (int k = 0; k < 3; k++) lo[k] = 1e300, hi[k] = -1e300;
+        double lo0 = 1e300, lo1 = 1e300, lo2 = 1e300, hi0 = -1e300, hi1 = -1e300, hi2 = -1e300; // (extrema: the same in any order)
+#pragma omp parallel for schedule(static) reduction(min : lo0, lo1, lo2) reduction(max : hi0, hi1, hi2) if (parallel_sort && sz >= 65536)
         for (int i = 0; i < sz; i++) {
             int u = T.perm[off + i];
-            for (int k = 0; k < d; k++) {
-                double x = T.coords[(size_t)u * d + k];
-                lo[k] = std::min(lo[k], x);
-                hi[k] = std::max(hi[k], x);
-            }
+            const double *x = &T.coords[(size_t)u * d];
+            lo0 = std::min(lo0, x[0]); hi0 = std::max(hi0, x[0]);
+            if (d > 1) { lo1 = std::min(lo1, x[1]); hi1 = std::max(hi1, x[1]); }
+            if (d > 2) { lo2 = std::min(lo2, x[2]); hi2 = std::max(hi2, x[2]); }
         }
+        lo[0] = lo0; lo[1] = lo1; lo[2] = lo2; hi[0] = hi0; hi[1] = hi1; hi[2] = hi2;
         int best = 0;
         for (int k = 1; k < d; k++)
             if (hi[k] - lo[k] > hi[best] - lo[best]) best = k;
@@ -199,7 +237,7 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
     std::iota(T.perm.begin(), T.perm.end(), 0);
     const int P = T.n_partition;
 
-    Geometry g0 = compute_geometry(T, a.radii, a.weights, 0, a.n_points);
+    Geometry g0 = compute_geometry(T, a.radii, a.weights, 0, a.n_points, true);
     push_node(T, 0, a.n_points, 0, -1, -1, g0);
     std::vector<int> level; // nodes to try to split next
     if (P == 1) {
@@ -233,7 +271,7 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
         T.n_child[0] = P;
         int off = 0;
         for (int p = 0; p < P; p++) {
-            Geometry g = compute_geometry(T, a.radii, a.weights, off, sizes[p]);
+            Geometry g = compute_geometry(T, a.radii, a.weights, off, sizes[p], true);
             int id = push_node(T, off, sizes[p], 1, 0, p, g);
             T.part_nodes.push_back(id);
             level.push_back(id);
@@ -270,7 +308,7 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
             s.ok = true;
             int o = off;
             for (int v : s.sizes) {
-                s.geo.push_back(compute_geometry(T, a.radii, a.weights, o, v));
+                s.geo.push_back(compute_geometry(T, a.radii, a.weights, o, v, !wide_level));
                 o += v;
             }
         };

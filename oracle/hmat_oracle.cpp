@@ -60,14 +60,24 @@ struct ClusterTree {
 
 enum Strategy { PCA_REGULAR = 0, PCA_GEOMETRIC = 1, BBOX_REGULAR = 2, BBOX_GEOMETRIC = 3 };
 
+// Sums over the points of a node run in blocks of SUM_BLOCK consecutive points (cluster order): a block is summed from zero, the
+// block sums are added in order (a node of at most SUM_BLOCK points: the plain running sum).  The order is part of the definition
+// here because it fixes the last bits of centres and split directions, hence the order of near-equal projections.
+static const int SUM_BLOCK = 4096;
+
 static void node_geometry(const ClusterTree &T, const double *radii, const double *weights, Node &nd) {
     const int d = T.d;
     double c[3] = {0, 0, 0}, wsum = 0;
-    for (int i = 0; i < nd.size; i++) {
-        int u     = T.perm[nd.offset + i];
-        double w  = weights ? weights[u] : 1.0;
-        wsum += w;
-        for (int k = 0; k < d; k++) c[k] += w * T.coords[(size_t)u * d + k];
+    for (int i0 = 0; i0 < nd.size; i0 += SUM_BLOCK) {
+        double cb[3] = {0, 0, 0}, wb = 0;
+        for (int i = i0; i < std::min(nd.size, i0 + SUM_BLOCK); i++) {
+            int u     = T.perm[nd.offset + i];
+            double w  = weights ? weights[u] : 1.0;
+            wb += w;
+            for (int k = 0; k < d; k++) cb[k] += w * T.coords[(size_t)u * d + k];
+        }
+        for (int k = 0; k < d; k++) c[k] += cb[k];
+        wsum += wb;
     }
     if (wsum != 0) for (int k = 0; k < d; k++) c[k] /= wsum;
     double rad = 0;
@@ -113,12 +123,16 @@ static std::vector<int> split_node(ClusterTree &T, const double *weights, const 
     double dir[3] = {1, 0, 0};
     if (strategy == PCA_REGULAR || strategy == PCA_GEOMETRIC) {
         double cov[3][3] = {{0}};
-        for (int i = 0; i < nd.size; i++) {
-            int u = T.perm[nd.offset + i];
-            double w = weights ? weights[u] : 1.0;
-            double t[3];
-            for (int k = 0; k < d; k++) t[k] = T.coords[(size_t)u * d + k] - nd.c[k];
-            for (int p = 0; p < d; p++) for (int q = 0; q < d; q++) cov[p][q] += w * t[p] * t[q];
+        for (int i0 = 0; i0 < nd.size; i0 += SUM_BLOCK) { // blocked sums, see node_geometry
+            double cb[3][3] = {{0}};
+            for (int i = i0; i < std::min(nd.size, i0 + SUM_BLOCK); i++) {
+                int u = T.perm[nd.offset + i];
+                double w = weights ? weights[u] : 1.0;
+                double t[3];
+                for (int k = 0; k < d; k++) t[k] = T.coords[(size_t)u * d + k] - nd.c[k];
+                for (int p = 0; p < d; p++) for (int q = 0; q < d; q++) cb[p][q] += w * t[p] * t[q];
+            }
+            for (int p = 0; p < d; p++) for (int q = 0; q < d; q++) cov[p][q] += cb[p][q];
         }
         principal_axis(cov, d, dir);
     } else {

@@ -382,3 +382,37 @@ def test_minimal_depths_of_the_block_tree(built, min_t, min_s):
     for t_off, m, s_off, n in list(np.asarray(adm)) + list(np.asarray(dns)):
         cover[t_off:t_off + m, s_off:s_off + n] += 1
     assert cover.min() == 1 and cover.max() == 1
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2, 3])
+def test_large_cluster_tree_is_the_same_for_every_thread_count_and_equals_the_oracle(built, oracle, strategy):
+    """Nodes of more than 4096 points sum their means and covariances in blocks (csrc/cluster.cpp: SUM_BLOCK) so that the top
+    levels of the tree can use all threads: the permutation and the node table must not depend on the thread count, and equal
+    the oracle's (which forms the same blocked sums serially).  Also the independent property check on the big tree."""
+    import Htool
+    from oracle import independent as I
+
+    rng = np.random.RandomState(7)
+    pts = rng.rand(3, 40000) * np.array([[1.0], [0.6], [0.3]])
+    w = rng.rand(40000) + 0.5
+    name = ["PCARegular", "PCAGeometric", "BoundingBoxRegular", "BoundingBoxGeometric"][strategy]
+    trees = []
+    for threads in (1, 3, 8):
+        Htool.set_num_threads(threads)
+        b = Htool.ClusterTreeBuilder()
+        b.set_maximal_leaf_size(50)
+        b.set_partitioning_strategy(getattr(Htool, name)())
+        cl = b.create_cluster_tree(pts, 2, size_of_partition=4, weights=w)
+        ints, dbl = cl._nodes()
+        trees.append((np.asarray(cl.get_permutation()).copy(), np.asarray(ints).copy(), np.asarray(dbl).copy()))
+    for t in trees[1:]:
+        assert np.array_equal(t[0], trees[0][0]) and np.array_equal(t[1], trees[0][1]) and np.array_equal(t[2], trees[0][2])
+    oc = oracle.Cluster(pts, n_children=2, size_of_partition=4, max_leaf=50, strategy=strategy, weights=w)
+    assert np.array_equal(oc.perm, trees[0][0])
+    # the node tables list the same nodes in another order (level by level here, depth first there): compare by (offset, size);
+    # centres and radii bit for bit (the blocked sums are the same sums)
+    mine = {(int(r[0]), int(r[1])): (int(r[2]), int(r[5]), int(r[6]), tuple(g)) for r, g in zip(trees[0][1], trees[0][2])}
+    theirs = {(int(r[0]), int(r[1])): (int(r[2]), int(r[5]), int(r[6]), tuple(g)) for r, g in zip(oc.inodes, oc.dnodes)}
+    assert mine == theirs
+    assert I.check_cluster_tree(trees[0][1], trees[0][2], trees[0][0], pts, 2, 50, strategy, weights=w) > 100
+    Htool.set_num_threads(8)
