@@ -51,7 +51,21 @@ class _Comm:
             import Htool
 
             uid = Htool.rccl_unique_id() if self.rank == 0 else None
-            uid = self.bcast(uid, root=0)
+            import torch.distributed as tdist
+
+            dist = tdist if tdist.is_initialized() else (self._dist() if self.size > 1 else None)
+            if dist is not None and dist.get_backend() == "nccl":
+                # the 128 bytes travel over the process group that is already there (a device tensor: no second, host-side
+                # group has to be set up just for them)
+                import torch
+
+                box = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if self.rank == 0:
+                    box.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+                dist.broadcast(box, src=0)
+                uid = bytes(box.cpu().numpy().tobytes())
+            else:
+                uid = self.bcast(uid, root=0)
             self._rccl = Htool.RcclCommunicator(uid, self.rank, self.size)
         return self
 
