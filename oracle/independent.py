@@ -1,5 +1,5 @@
-"""Independent numpy checks of the cluster tree and of ACA -- a SECOND formulation, sharing no code and no
-recurrences with oracle/hmat_oracle.cpp or with the product's host code.
+"""Independent numpy checks of the cluster tree, of the block tree and of ACA -- a SECOND formulation, sharing no code and
+no recurrences with oracle/hmat_oracle.cpp or with the product's host code.
 
 TEST INFRASTRUCTURE ONLY (same rule as the rest of oracle/): imported by tests/ only.
 
@@ -16,6 +16,9 @@ from the DEFINITIONS instead:
   * ACA (compressor contract src/htool/hmatrix/interfaces/virtual_low_rank_generator.hpp:25-45):
     `aca_full_residual` keeps the EXPLICIT residual matrix R = A - sum u_k v_k and measures |sum u_k v_k|_F on the
     explicit matrix, where the engines use the implicit row/column updates and the running estimate.
+  * block tree (SURVEY.md Appendix A.3; replaces htool::HMatrixTreeBuilder::build, hmatrix_tree_builder.hpp:36): `check_block_tree`
+    never runs the top-down visit -- leaves must be stopping places, reachable by walking UP through pairs whose split rule
+    produces them, and tile the matrix exactly.
   * the acceptance semantics of epsilon of the reference's own compressor
     (example/advanced/define_custom_low_rank_generator.py:16-27): `svd_rank`.
 """
