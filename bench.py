@@ -261,14 +261,14 @@ def main():
             free_b, _total_b = torch.cuda.mem_get_info()
             t_prep = time.time()
             try:
-                touch = torch.empty(int(free_b * 0.8), dtype=torch.uint8, device="cuda")
+                touch = torch.empty(int(free_b * 0.92), dtype=torch.uint8, device="cuda")
                 torch.cuda.synchronize()
                 t_alloc = time.time() - t_prep
                 del touch
                 torch.cuda.empty_cache()
-                wait_s = 1.0 + 0.06 * free_b * 0.8 / 1e9
+                wait_s = 1.0 + 0.06 * free_b * 0.92 / 1e9
                 time.sleep(wait_s)
-                vram_prep = {"touched_GB": free_b * 0.8 / 1e9, "alloc_s": t_alloc, "wait_s": wait_s}
+                vram_prep = {"touched_GB": free_b * 0.92 / 1e9, "alloc_s": t_alloc, "wait_s": wait_s}
             except RuntimeError as e:  # (someone else holds the memory: the build will say so itself if it does not fit)
                 torch.cuda.empty_cache()
                 vram_prep = {"skipped": repr(e)[:200]}
