@@ -6,6 +6,7 @@ from htool_python_amd.workloads import points_in_sphere
 kernel = sys.argv[1] if len(sys.argv) > 1 else "laplace"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+eps = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
 pts=points_in_sphere(n, seed=0)
 Htool.set_num_threads(16)
 for rep in range(reps):
@@ -15,10 +16,10 @@ for rep in range(reps):
     t1=time.time()
     if kernel == "helmholtz":
         gen=Htool.ComplexNativeGenerator("helmholtz",pts,pts,10.0)
-        b=Htool.ComplexHMatrixTreeBuilder(1e-3,10.0,"N","N")
+        b=Htool.ComplexHMatrixTreeBuilder(eps,10.0,"N","N")
     else:
         gen=Htool.NativeGenerator("laplace",pts,pts,0.0)
-        b=Htool.HMatrixTreeBuilder(1e-3,10.0,"N","N")
+        b=Htool.HMatrixTreeBuilder(eps,10.0,"N","N")
     torch.cuda.synchronize(); t2=time.time()
     H=b.build(gen,cl,cl)
     torch.cuda.synchronize(); t3=time.time()
