@@ -305,19 +305,22 @@ def main():
         builder.set_symmetric_storage(args.symmetric == "one-triangle")
     torch.cuda.synchronize()
     t0 = time.time()
-    dist_op, rccl_error = None, None
-    if dist_mode and args.backend == "nccl":
+    dist_op, rccl_error, in_library = None, None, False
+    if dist_mode:
         # the reference's decomposition through its own entry point (DefaultApproximationBuilder, utility.hpp:26): rank p builds
         # rows(partition p) x all columns; the communicator carries a library-owned RCCL handle, so the exchange of every
-        # product runs inside the library on device buffers (htool_distributed_matvec_device)
+        # product runs inside the library on device buffers (htool_distributed_matvec_device).  --backend gloo (rehearsal, ranks
+        # sharing a GPU): the SAME library call, its all-gather staged through the host by the library (htool_comm without
+        # allgather_device)
         import mpi4py
 
         comm = mpi4py.MPI.COMM_WORLD
         rccl_error = None
-        try:
-            comm.use_rccl()
-        except Exception as e:  # reported in the JSON line ("exchange"); the exchange then goes through torch.distributed (also RCCL)
-            rccl_error = repr(e)
+        if args.backend == "nccl":
+            try:
+                comm.use_rccl()
+            except Exception as e:  # reported in the JSON line ("exchange"); the exchange then goes through torch.distributed (also RCCL)
+                rccl_error = repr(e)
         approx = Htool.DefaultApproximationBuilder(gen, cluster, cluster, builder, comm)
         dist_op = approx.distributed_operator
         H = approx.hmatrix
@@ -369,13 +372,15 @@ def main():
 
         gather = SliceGatherer(sizes, dtype, "cuda")
 
-        if dist_op is not None and dist_op.has_rccl:
+        in_library = dist_op is not None and dist_op.exchange_kind(1) >= 0 and (dist_op.has_rccl or args.backend == "gloo")
+        if in_library:
             def step():
-                # one library call: RCCL all-gather of the x slices over xGMI + compaction + the local product, on one stream
+                # one library call: all-gather of the x slices (RCCL over xGMI; host-staged in a gloo rehearsal) + compaction +
+                # the local product, on one stream
                 dist_op.matvec_device(x_local.data_ptr(), y.data_ptr(), stream)
         else:
             def step():
-                # rehearsal path (gloo, ranks sharing a GPU): host-staged exchange, then the local product
+                # the library communicator could not be set up: torch.distributed all-gather (also RCCL), then the local product
                 x_full = gather(x_local)
                 H.matvec_device(x_full.data_ptr(), y.data_ptr(), 1, stream)
 
@@ -516,10 +521,11 @@ def main():
         "symmetric_storage": args.symmetric,
         "per_rank": per_rank,   # multi-GPU: bytes, product time (sum of its kernels, HIP events) and exchange time of every rank
         "rel_err_sampled_rows": rel_err,
-        "exchange": None if not dist_mode else ("htool_distributed_matvec_device: ncclAllGather of the x slices + compaction + local product inside the library, one stream"
-                                                if dist_op is not None and dist_op.has_rccl else
-                                                (f"torch.distributed all_gather_into_tensor (RCCL) + local product; library communicator unavailable: {rccl_error}"
-                                                 if args.backend == "nccl" else "host-staged gloo all-gather (rehearsal)")),
+        "exchange": None if not dist_mode else (
+            ("htool_distributed_matvec_device: ncclAllGather of the x slices + compaction + local product inside the library, one stream" if dist_op.has_rccl else
+             "htool_distributed_matvec_device: inside the library, all-gather staged through the host (gloo rehearsal: ranks share a GPU; not a benchmark)")
+            + f" [exchange kind {dist_op.exchange_kind(1)}]"
+            if in_library else f"torch.distributed all_gather_into_tensor (RCCL) + local product; library communicator unavailable: {rccl_error}"),
     }
     if gmres_info is not None:
         # true residual and solution error of the timed solve (use_ddm_solver.py:60-61, tests/test_ddm_solver.py:659-660)

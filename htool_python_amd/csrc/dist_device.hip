@@ -76,6 +76,19 @@ int rccl_host_allgatherv(void *ctx, const void *send, int64_t send_bytes, void *
     return 0;
 }
 
+// htool_comm.allgather_device of an RCCL communicator: equal slices on device buffers, in stream order
+int rccl_allgather_device(void *ctx, const void *send_dev, void *recv_dev, int64_t bytes, void *stream) {
+    RcclComm *c = static_cast<RcclComm *>(ctx);
+    try {
+        HM_CHECK(c && c->comm, "RCCL communicator already destroyed");
+        RCCL_OK(ncclAllGather(send_dev, recv_dev, (size_t)bytes, ncclUint8, c->comm, (hipStream_t)stream));
+    } catch (const std::exception &e) {
+        htool_error_slot() = e.what();
+        return 1;
+    }
+    return 0;
+}
+
 // gathered[p][c][0 : pad)  ->  x_full[c][displs[p] : displs[p] + counts[p])   (one launch for all ranks and columns)
 template <typename T>
 __global__ void compact_slices_kernel(const T *__restrict__ gathered, T *__restrict__ x_full, const int *__restrict__ counts, const int *__restrict__ displs, int pad, int mu,
@@ -93,12 +106,22 @@ struct DistDeviceState {
     int *counts = nullptr, *displs = nullptr;
     int pad = 0, mu_cap = 0;
     bool equal = false;
+    // pinned host buffers of the host-staged exchange (communicators without allgather_device)
+    void *h_send = nullptr, *h_recv = nullptr;
+    size_t h_cap = 0;
     ~DistDeviceState() {
         (void)hipSetDevice(device);
         for (void *p : {send, recv, x_full, (void *)counts, (void *)displs}) if (p) (void)hipFree(p);
+        if (h_send) (void)hipHostFree(h_send);
+        if (h_recv) (void)hipHostFree(h_recv);
     }
 };
 void dist_device_free(DistDeviceState *s) { delete s; }
+
+static bool force_padded() { // tests: take the padded-slices path even for equal slices / one rank
+    const char *f = getenv("HTOOL_DIST_FORCE_PADDED");
+    return f && f[0] == '1';
+}
 
 static DistDeviceState *dist_state(htool_distributed *d, int mu) {
     const HMatrix &H = d->hmat->H;
@@ -115,10 +138,10 @@ static DistDeviceState *dist_state(htool_distributed *d, int mu) {
         cnt[p] = (int)d->s_counts[p];
         dsp[p] = (int)d->s_displs[p];
         pad = std::max(pad, cnt[p]);
-        equal = equal && cnt[p] == cnt[0];
+        // zero-copy needs rank p's slice at p * pad of the gathered vector: equal counts AND partitions in rank order
+        equal = equal && cnt[p] == cnt[0] && d->s_displs[p] == (int64_t)p * cnt[0];
     }
-    if (const char *f = getenv("HTOOL_DIST_FORCE_PADDED")) // tests: take the padded-slices path even for equal slices / one rank
-        if (f[0] == '1') equal = false;
+    if (force_padded()) equal = false;
     s->pad = pad;
     s->equal = equal;
     s->mu_cap = mu;
@@ -135,6 +158,47 @@ static DistDeviceState *dist_state(htool_distributed *d, int mu) {
     return d->dev;
 }
 
+// the exchange step: every rank contributes `bytes` bytes at send_dev, recv_dev receives rank p's at p * bytes (stream order)
+static void gather_equal_slices(htool_distributed *d, DistDeviceState *s, const void *send_dev, void *recv_dev, size_t bytes, hipStream_t st) {
+    const int P = d->comm.size;
+    if (d->comm.allgather_device) { // RCCL over xGMI (or the host language's own device all-gather)
+        const int rc = d->comm.allgather_device(d->comm.ctx, send_dev, recv_dev, (int64_t)bytes, (void *)st);
+        HM_CHECK(rc == 0, std::string("distributed device product: allgather_device failed: ") + htool_error_slot());
+        return;
+    }
+    // host-staged (several ranks on one GPU): device -> pinned host, the communicator's host all-gather, pinned host -> device
+    HM_CHECK(d->comm.allgatherv != nullptr, "distributed device product: the communicator has neither allgather_device (htool_comm_init_rccl / htool_comm_wrap_rccl) nor allgatherv");
+    if (bytes > s->h_cap) {
+        if (s->h_send) (void)hipHostFree(s->h_send);
+        if (s->h_recv) (void)hipHostFree(s->h_recv);
+        s->h_send = s->h_recv = nullptr;
+        s->h_cap = 0;
+        HIP_OK(hipHostMalloc(&s->h_send, bytes, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc(&s->h_recv, bytes * P, hipHostMallocDefault));
+        s->h_cap = bytes;
+    }
+    HIP_OK(hipMemcpyAsync(s->h_send, send_dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st)); // (also: the host -> device copy of the previous call has left h_recv)
+    std::vector<int64_t> cnt((size_t)P, (int64_t)bytes), dsp((size_t)P);
+    for (int p = 0; p < P; p++) dsp[p] = (int64_t)p * (int64_t)bytes;
+    const int rc = d->comm.allgatherv(d->comm.ctx, s->h_send, (int64_t)bytes, s->h_recv, cnt.data(), dsp.data());
+    HM_CHECK(rc == 0, "distributed device product: allgatherv failed");
+    HIP_OK(hipMemcpyAsync(recv_dev, s->h_recv, bytes * P, hipMemcpyHostToDevice, st));
+}
+
+template <typename T>
+static void launch_compact(const void *gathered, void *x_full, const int *counts_dev, const int *displs_dev, int P, int pad, int mu, long long ldx, hipStream_t st) {
+    if (pad <= 0 || P <= 0 || mu <= 0) return;
+    HM_CHECK(P <= 65535 && mu <= 65535, "compaction: too many ranks / columns for one launch");
+    const dim3 grid((unsigned)((pad + 255) / 256), (unsigned)P, (unsigned)mu), block(256);
+    hipLaunchKernelGGL(compact_slices_kernel<T>, grid, block, 0, st, (const T *)gathered, (T *)x_full, counts_dev, displs_dev, pad, mu, ldx);
+    HIP_OK(hipGetLastError());
+}
+
+static bool single_owner(const htool_distributed *d) { // one rank owns everything and nothing asks for an exchange
+    return d->comm.size == 1 && !d->comm.allgather_device && !force_padded();
+}
+
 // Y_local = A[rows of this rank, :] X with X given by its local slices: column c of X_local holds this rank's part
 // (source partition `rank`, cluster numbering) at X_local + c * ldx; Y_local + c * ldy receives the rank's rows.
 static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_t ldx, void *Y_local, int64_t ldy, int mu, hipStream_t caller_stream) {
@@ -145,30 +209,27 @@ static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_
     HM_CHECK(mu >= 1, "mu must be >= 1");
     HM_CHECK(H.dev != nullptr, "H-matrix has no device data");
     if (!st) st = H.dev->stream; // the exchange and the product have to share one stream
-    if (P == 1 && !d->comm.rccl) { // one rank owns everything and there is no RCCL handle: the slice is the whole vector
+    if (single_owner(d)) { // the slice is the whole vector
         device_matmat_device(H, X_local, (long long)ldx, Y_local, (long long)ldy, mu, 1, caller_stream);
         return;
     }
-    RcclComm *rc = static_cast<RcclComm *>(d->comm.rccl);
-    HM_CHECK(rc != nullptr && rc->comm != nullptr, "distributed device product: the communicator carries no RCCL handle (htool_comm_init_rccl / htool_comm_wrap_rccl)");
     DistDeviceState *s = dist_state(d, mu);
     HIP_OK(hipSetDevice(s->device));
+    HM_CHECK(rank >= 0 && rank < P, "distributed device product: rank out of range");
     const int mine = (int)d->s_counts[rank];
     const size_t ns = (size_t)d->sc->n_points;
     if (s->equal && mu == 1) {
         // equal slices: gather straight from the caller's buffer into the contiguous vector (displs[p] = p * pad)
-        RCCL_OK(ncclAllGather(X_local, s->x_full, (size_t)s->pad * es, ncclUint8, rc->comm, st));
+        gather_equal_slices(d, s, X_local, s->x_full, (size_t)s->pad * es, st);
     } else {
         if (mu == 1) HIP_OK(hipMemcpyAsync(s->send, X_local, (size_t)mine * es, hipMemcpyDeviceToDevice, st));
         else {
             HM_CHECK(ldx >= mine, "distributed device product: ldx is smaller than this rank's slice");
             HIP_OK(hipMemcpy2DAsync(s->send, (size_t)s->pad * es, X_local, (size_t)ldx * es, (size_t)mine * es, (size_t)mu, hipMemcpyDeviceToDevice, st));
         }
-        RCCL_OK(ncclAllGather(s->send, s->recv, (size_t)s->pad * mu * es, ncclUint8, rc->comm, st));
-        const dim3 grid((unsigned)((s->pad + 255) / 256), (unsigned)P, (unsigned)mu), block(256);
-        if (H.is_complex) hipLaunchKernelGGL(compact_slices_kernel<double2>, grid, block, 0, st, (const double2 *)s->recv, (double2 *)s->x_full, s->counts, s->displs, s->pad, mu, (long long)ns);
-        else hipLaunchKernelGGL(compact_slices_kernel<double>, grid, block, 0, st, (const double *)s->recv, (double *)s->x_full, s->counts, s->displs, s->pad, mu, (long long)ns);
-        HIP_OK(hipGetLastError());
+        gather_equal_slices(d, s, s->send, s->recv, (size_t)s->pad * mu * es, st);
+        if (H.is_complex) launch_compact<double2>(s->recv, s->x_full, s->counts, s->displs, P, s->pad, mu, (long long)ns, st);
+        else launch_compact<double>(s->recv, s->x_full, s->counts, s->displs, P, s->pad, mu, (long long)ns, st);
     }
     device_matmat_device(H, s->x_full, (long long)ns, Y_local, (long long)ldy, mu, 1, caller_stream); // (NULL: the operator's own stream, = st)
 }
@@ -198,6 +259,7 @@ int htool_comm_init_rccl(const void *id128, int rank, int size, htool_comm *out)
     out->rank = rank;
     out->size = size;
     out->allgatherv = &rccl_host_allgatherv;
+    out->allgather_device = &rccl_allgather_device;
     out->rccl = c.get();
     out->ctx = c.release();
     API_END
@@ -215,6 +277,7 @@ int htool_comm_wrap_rccl(void *nccl_comm, int rank, int size, htool_comm *out) {
     out->rank = rank;
     out->size = size;
     out->allgatherv = &rccl_host_allgatherv;
+    out->allgather_device = &rccl_allgather_device;
     out->rccl = c.get();
     out->ctx = c.release();
     API_END
@@ -225,6 +288,7 @@ void htool_comm_destroy_rccl(htool_comm *c) {
         delete static_cast<RcclComm *>(c->rccl);
         c->rccl = c->ctx = nullptr;
         c->allgatherv = nullptr;
+        c->allgather_device = nullptr;
     }
 }
 
@@ -237,6 +301,36 @@ int htool_distributed_matvec_device(htool_distributed *d, const void *x_local_de
 int htool_distributed_matmat_device(htool_distributed *d, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream) {
     API_BEGIN
     dist_matmat_device(d, X_local_dev, ldx, Y_local_dev, ldy, mu, (hipStream_t)stream);
+    API_END
+}
+
+int htool_distributed_exchange_kind(const htool_distributed *d, int mu) {
+    if (!d || single_owner(d)) return 0;
+    if ((int)d->s_counts.size() != d->comm.size) return -1; // the source tree carries no partition of the communicator's size
+    bool equal = !force_padded();
+    for (int p = 0; equal && p < d->comm.size; p++) equal = d->s_counts[p] == d->s_counts[0] && d->s_displs[p] == (int64_t)p * d->s_counts[0];
+    const int kind = (equal && mu == 1) ? 1 : 2;
+    return d->comm.allgather_device ? kind : kind + 2;
+}
+
+int htool_debug_compact_slices(const void *gathered_dev, void *x_full_dev, const int *counts, const int *displs, int P, int pad, int mu, int64_t ldx, int is_complex,
+                               void *stream) {
+    API_BEGIN
+    HM_CHECK(gathered_dev && x_full_dev && counts && displs && P >= 1 && pad >= 0 && mu >= 1, "htool_debug_compact_slices: bad argument");
+    for (int p = 0; p < P; p++) HM_CHECK(counts[p] >= 0 && counts[p] <= pad && displs[p] >= 0 && (int64_t)displs[p] + counts[p] <= ldx, "htool_debug_compact_slices: slice out of range");
+    int *tab = nullptr;
+    HIP_OK(hipMalloc((void **)&tab, sizeof(int) * 2 * (size_t)P));
+    try {
+        HIP_OK(hipMemcpy(tab, counts, sizeof(int) * P, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(tab + P, displs, sizeof(int) * P, hipMemcpyHostToDevice));
+        if (is_complex) launch_compact<double2>(gathered_dev, x_full_dev, tab, tab + P, P, pad, mu, (long long)ldx, (hipStream_t)stream);
+        else launch_compact<double>(gathered_dev, x_full_dev, tab, tab + P, P, pad, mu, (long long)ldx, (hipStream_t)stream);
+        HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    } catch (...) {
+        (void)hipFree(tab);
+        throw;
+    }
+    (void)hipFree(tab);
     API_END
 }
 

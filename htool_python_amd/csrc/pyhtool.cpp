@@ -712,6 +712,9 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 check(htool_distributed_matmat_device(o.d, (const void *)x_local, ldx, (void *)y_local, ldy, mu, (void *)stream));
             }, "x_local_ptr"_a, "ldx"_a, "y_local_ptr"_a, "ldy"_a, "mu"_a, "stream"_a = 0)
         .def_property_readonly("has_rccl", [](Op &o) { return o.comm->c.rccl != nullptr; })
+        // which exchange matvec_device / matmat_device run (htool_distributed_exchange_kind): 0 none, 1 zero-copy, 2 padded + compaction,
+        // 3 / 4 the same staged through the host all-gather of the communicator object, -1 not possible
+        .def("exchange_kind", [](Op &o, int mu) { return htool_distributed_exchange_kind(o.d, mu); }, "mu"_a = 1)
         .def_property_readonly("comm", [](Op &o) { return o.comm->obj; })
         .def("partition", [](Op &o) {
                 std::vector<std::pair<int, int>> out;

@@ -178,9 +178,15 @@ class DistributedOperator:
         the vector slices inside the library (htool_distributed_matvec_device)."""
         return self._core is not None and self._core.has_rccl
 
+    def exchange_kind(self, mu=1):
+        """Which exchange matvec_device / matmat_device run inside the library (htool_distributed_exchange_kind): 0 none (one
+        rank), 1 all-gather straight into the contiguous vector, 2 padded slices + compaction kernel, 3 / 4 the same with the
+        all-gather staged through the host (communicator without RCCL handle: ranks sharing a GPU), -1 not available."""
+        return self._core.exchange_kind(mu) if self.has_only_default_operator() else -1
+
     def matvec_device(self, x_local_ptr, y_local_ptr, stream=0):
         """GPU-resident product of the default operator: this rank's slice of x in, its rows of y out (device pointers,
-        cluster numbering); the all-gather of the slices is RCCL inside the library."""
+        cluster numbering); the all-gather of the slices happens inside the library (RCCL, or host-staged: exchange_kind)."""
         if not self.has_only_default_operator():
             raise RuntimeError("matvec_device: only the default H-matrix operator has a device-resident product")
         self._core.matvec_device(x_local_ptr, y_local_ptr, stream)

@@ -42,9 +42,10 @@ class DeviceOperator:
     """y_local = (shift I + A) x on GPU-resident slices in cluster numbering; A = this rank's rows."""
 
     def __init__(self, hmatrix, partition=None, rank=0, group=None, shift=0.0, dist_op=None):
-        # dist_op: the DistributedOperator this H-matrix belongs to; when its communicator carries a library-owned RCCL
-        # handle the exchange + product of apply() is ONE library call (htool_distributed_matvec_device)
-        self.dist_op = dist_op if (dist_op is not None and getattr(dist_op, "has_rccl", False)) else None
+        # dist_op: the DistributedOperator this H-matrix belongs to; the exchange + product of apply() is then ONE library call
+        # (htool_distributed_matvec_device: RCCL all-gather when the communicator carries a library-owned handle, the same
+        # code path staged through the host all-gather of the communicator object when ranks share a GPU)
+        self.dist_op = dist_op if (dist_op is not None and hasattr(dist_op, "exchange_kind") and dist_op.exchange_kind(1) >= 0) else None
         self.H = hmatrix
         self.n = hmatrix.shape[1]
         self.partition = partition or [(0, self.n)]
@@ -54,28 +55,54 @@ class DeviceOperator:
         self.products = 0
         self._gather = None
 
-    def apply(self, x_local):
-        y = torch.empty(self.size, dtype=x_local.dtype, device=x_local.device)
+    def apply(self, x_local, out=None):
+        """x_local: this rank's slice, shape (size,) or (mu, size) (rows may be strided: a slot of a Krylov basis); the result goes
+        to `out` (same shapes) when given."""
+        if x_local.dim() == 2:
+            return self._apply_multi(x_local, out)
+        y = torch.empty(self.size, dtype=x_local.dtype, device=x_local.device) if out is None else out
+        assert y.is_contiguous() and y.numel() == self.size
         stream = torch.cuda.current_stream().cuda_stream
         if self.dist_op is not None:
             self.dist_op.matvec_device(x_local.contiguous().data_ptr(), y.data_ptr(), stream)
-            self.products += 1
-            if self.shift != 0.0:
-                y += self.shift * x_local
-            return y
-        if self.world == 1:
-            xf = x_local.contiguous()
         else:
-            if self._gather is None:
-                from .comm import SliceGatherer
-
-                self._gather = SliceGatherer([s for _, s in self.partition], x_local.dtype, x_local.device, self.group)
-            xf = self._gather(x_local)
-        self.H.matvec_device(xf.data_ptr(), y.data_ptr(), 1, stream)
+            xf = x_local.contiguous() if self.world == 1 else self._gathered(x_local)
+            self.H.matvec_device(xf.data_ptr(), y.data_ptr(), 1, stream)
         self.products += 1
         if self.shift != 0.0:
-            y += self.shift * x_local
+            y.add_(x_local, alpha=self.shift)
         return y
+
+    apply.supports_out = True
+
+    def _gathered(self, x_local):
+        if self._gather is None:
+            from .comm import SliceGatherer
+
+            self._gather = SliceGatherer([s for _, s in self.partition], x_local.dtype, x_local.device, self.group)
+        return self._gather(x_local)
+
+    def _apply_multi(self, X, out=None):
+        """mu right-hand sides in one call (one exchange, sweeps of 8 / 16 columns over the panels): X (mu, size), row c = column c."""
+        mu = X.shape[0]
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        Y = torch.empty(mu, self.size, dtype=X.dtype, device=X.device) if out is None else out
+        assert Y.stride(1) == 1 and Y.shape == (mu, self.size)
+        stream = torch.cuda.current_stream().cuda_stream
+        ldx = X.stride(0) if mu > 1 else max(self.size, 1)
+        ldy = Y.stride(0) if mu > 1 else max(self.size, 1)
+        if self.dist_op is not None:
+            self.dist_op.matmat_device(X.data_ptr(), ldx, Y.data_ptr(), ldy, mu, stream)
+        elif self.world == 1:
+            self.H.matmat_device(X.data_ptr(), ldx, Y.data_ptr(), ldy, mu, 1, stream)
+        else:
+            for c in range(mu):
+                self.H.matvec_device(self._gathered(X[c]).data_ptr(), Y[c].data_ptr(), 1, stream)
+        self.products += mu
+        if self.shift != 0.0:
+            Y.add_(X, alpha=self.shift)
+        return Y
 
     def reduce(self, t):
         if self.world > 1:
@@ -113,6 +140,13 @@ class BlockJacobi:
         self.nb, self.bmax = len(ids), bmax
 
     def __call__(self, v):
+        """v: (size,) or (mu, size) -- the blocks are solved for all columns at once."""
+        if v.dim() == 2:
+            mu = v.shape[0]
+            pad = torch.zeros(mu, self.nb * self.bmax, dtype=v.dtype, device=v.device)
+            pad[:, self.index] = v
+            sol = torch.linalg.lu_solve(self.lu, self.piv, pad.view(mu, self.nb, self.bmax).permute(1, 2, 0).contiguous())
+            return sol.permute(2, 0, 1).reshape(mu, -1)[:, self.index]
         pad = torch.zeros(self.nb * self.bmax, dtype=v.dtype, device=v.device)
         pad[self.index] = v
         sol = torch.linalg.lu_solve(self.lu, self.piv, pad.view(self.nb, self.bmax, 1))
@@ -157,38 +191,50 @@ class Solver:
         _parse_hpddm(hpddm_args, self._opts)
 
     def solve(self, x, b, hpddm_args=""):
-        """x (in/out, numpy, user numbering) <- solution of A x = b; several right-hand sides column by column."""
+        """x (in/out, numpy, user numbering) <- solution of A x = b; several right-hand sides are solved in lockstep (one product
+        call per iteration for all of them)."""
         _parse_hpddm(hpddm_args, self._opts)
         if b.ndim != x.ndim or (b.ndim == 2 and b.shape[1] != x.shape[1]) or b.ndim > 2:
             raise ValueError(f"Wrong dimension for right-hand side or solution\nright-hand side: {b.shape}\nsolution: {x.shape}\n")
-        cols = [(x, b)] if b.ndim == 1 else [(x[:, c], b[:, c]) for c in range(b.shape[1])]
         off, size = self.op.offset, self.op.size
         t0 = time.time()
-        its, res = [], []
-        for xc, bc in cols:
-            bl = torch.from_numpy(np.ascontiguousarray(np.asarray(bc)[self._perm][off:off + size])).cuda()
-            x0 = None
-            if np.any(np.asarray(xc) != 0):
-                x0 = torch.from_numpy(np.ascontiguousarray(np.asarray(xc)[self._perm][off:off + size])).cuda()
-            xl, info = self._gmres(self.op.apply, bl, x0, self._opts["tol"], self._opts["restart"], self._opts["max_it"], self.op.reduce if self.op.world > 1 else None,
-                                   precond=self._precond)
-            full = self._gather(xl)
-            out = np.empty_like(full)
-            out[self._perm] = full
-            xc[...] = out
-            its.append(info["iterations"])
-            res.append(info["residuals"][-1] if info["residuals"] else 0.0)
-            self._history = info["residuals"]
-        self._info = {"Nb_it": str(max(its)), "Relative_residual": str(max(res)), "Solve_seconds": str(time.time() - t0),
+        B2 = np.asarray(b).reshape(len(self._perm), -1)   # columns = right-hand sides
+        X2 = np.asarray(x).reshape(len(self._perm), -1)
+        mu = B2.shape[1]
+        # all right-hand sides in lockstep: one product call per iteration for the whole block (krylov.gmres, batched form)
+        bl = torch.from_numpy(np.ascontiguousarray(B2[self._perm][off:off + size].T)).cuda()
+        x0 = None
+        if np.any(X2 != 0):
+            x0 = torch.from_numpy(np.ascontiguousarray(X2[self._perm][off:off + size].T)).cuda()
+        red = self.op.reduce if self.op.world > 1 else None
+        if mu == 1:
+            xl, info = self._gmres(self.op.apply, bl[0], None if x0 is None else x0[0], self._opts["tol"], self._opts["restart"], self._opts["max_it"], red, precond=self._precond)
+            xl = xl.unsqueeze(0)
+            hist = [info["residuals"]]
+        else:
+            xl, info = self._gmres(self.op.apply, bl, x0, self._opts["tol"], self._opts["restart"], self._opts["max_it"], red, precond=self._precond)
+            hist = info["residuals"]
+        full = self._gather(xl)          # (mu, n) in cluster numbering
+        out = np.empty_like(full)
+        out[:, self._perm] = full
+        if b.ndim == 1:
+            x[...] = out[0]
+        else:
+            x[...] = out.T
+        self._history = hist[-1]
+        res = [h[-1] if h else 0.0 for h in hist]
+        self._info = {"Nb_it": str(info["iterations"]), "Relative_residual": str(max(res)), "Solve_seconds": str(time.time() - t0),
                       "Products": str(self.op.products), "Krylov_method": "gmres",
                       "Preconditioner": "none" if self._precond is None else "block-jacobi (dense diagonal leaves)"}
 
     def _gather(self, xl):
+        """(mu, local size) device -> (mu, n) host, cluster numbering."""
         if self.op.world == 1:
             return xl.cpu().numpy()
         from .comm import SliceGatherer
 
-        return SliceGatherer([s for _, s in self.op.partition], xl.dtype, xl.device, self.op.group)(xl).cpu().numpy()
+        gather = SliceGatherer([s for _, s in self.op.partition], xl.dtype, xl.device, self.op.group)
+        return np.stack([gather(xl[c]).cpu().numpy() for c in range(xl.shape[0])])
 
     def get_information(self):
         return dict(self._info)

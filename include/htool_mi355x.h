@@ -259,6 +259,14 @@ typedef struct htool_comm {
     void *ctx;
     int (*allgatherv)(void *ctx, const void *send, int64_t send_bytes, void *recv, const int64_t *recv_bytes, const int64_t *displs);
     void *rccl; /* opaque; NULL for a host-only communicator */
+    /* (c) the exchange step of the GPU-resident product (htool_distributed_matvec_device): all-gather of EQUAL slices of
+     * `bytes` bytes on DEVICE buffers, enqueued on `stream` (hipStream_t) -- recv_dev receives size * bytes, rank p's slice at
+     * p * bytes.  htool_comm_init_rccl / _wrap_rccl install ncclAllGather here.  NULL on a communicator that has only (b):
+     * the library then stages the slices through pinned host memory and allgatherv (device -> host, stream synchronised,
+     * allgatherv, host -> device): slower, but the product runs the same code path -- counts, displacements, padded slices,
+     * compaction, local product -- with several ranks sharing ONE GPU (tests, rehearsals).  A host language may also install
+     * its own (the ctypes tests do, to play rank r of P in a single process). */
+    int (*allgather_device)(void *ctx, const void *send_dev, void *recv_dev, int64_t bytes, void *stream);
 } htool_comm;
 /* RCCL bootstrap (the NCCL pattern): ONE rank obtains a unique id, the host language broadcasts its 128 bytes to the
  * other ranks by its own means, then every rank calls htool_comm_init_rccl on the device it selected with
@@ -286,10 +294,21 @@ int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, 
  * source partition `rank`, cluster numbering, device memory) and receives ITS rows of y (target partition `rank`, cluster
  * numbering).  The library gathers the slices with ONE ncclAllGather (zero-copy for equal slices, padded slices plus one
  * compaction kernel otherwise) and multiplies, all on `stream` (hipStream_t; NULL: the operator's own stream) without any
- * host synchronisation.  Needs a communicator with an RCCL handle (or a single rank) and a source tree partitioned like
- * the target tree.  The matmat form takes mu columns (column c at X_local + c * ldx elements) in one exchange. */
+ * host synchronisation.  Needs a source tree partitioned like the target tree and a communicator with an RCCL handle
+ * (htool_comm.allgather_device; without one the slices are staged through the host and allgatherv, see htool_comm).
+ * The matmat form takes mu columns (column c at X_local + c * ldx elements) in one exchange. */
 int htool_distributed_matvec_device(htool_distributed *d, const void *x_local_dev, void *y_local_dev, void *stream);
 int htool_distributed_matmat_device(htool_distributed *d, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream);
+/* which exchange the device product of this operator uses: 0 none (one rank owns everything), 1 the communicator's
+ * allgather_device straight into the contiguous vector (equal slices, one column), 2 the same on padded slices followed by
+ * the compaction kernel, 3 / 4 = 1 / 2 staged through the host (no allgather_device); -1: no device exchange possible (the
+ * source tree carries no partition of the communicator's size).  mu as in the matmat call. */
+int htool_distributed_exchange_kind(const htool_distributed *d, int mu);
+/* diagnostic entry for the unit test of the compaction kernel of the padded exchange: gathered_dev is [P][mu][pad]
+ * elements (what the all-gather of padded slices delivers), x_full_dev receives column c at c * ldx with rank p's slice at
+ * displs[p] .. displs[p] + counts[p] (counts / displs: host arrays of P ints). */
+int htool_debug_compact_slices(const void *gathered_dev, void *x_full_dev, const int *counts, const int *displs, int P, int pad, int mu, int64_t ldx,
+                               int is_complex, void *stream);
 
 #ifdef __cplusplus
 }
