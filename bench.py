@@ -29,11 +29,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 
 
 def kernel_source_sha1():
-    """Fingerprint of the product kernels' source: committed PMC measurements are only quoted for the code they were taken on."""
+    """Fingerprint of every source that decides what the dominant kernel reads -- the kernels, the panel layout and packing, the
+    launch classes: committed PMC measurements are only quoted for the code they were taken on."""
     import hashlib
 
     h = hashlib.sha1()
-    for name in ("product_kernels.inc", "device_tables.inc"):
+    for name in ("product_kernels.inc", "product_mfma.inc", "device_tables.inc", "pack_kernels.inc", "layout.cpp", "blocktree.cpp", "device.hip"):
         with open(os.path.join(ROOT, "htool_python_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -45,7 +46,7 @@ def pmc_traffic(args, n):
     (the file records the fingerprint of the kernel source it was measured on)."""
     if not (n == 1_000_000 and args.kernel == "laplace" and args.eps == 1e-3 and args.eta == 10.0 and args.leaf == 100 and args.gpus == 1 and args.rhs == 1):
         return None
-    for name in ("r02_pmc_hbm_traffic_1m_laplace.json", "r01_pmc_hbm_traffic_1m_laplace.json"):
+    for name in ("r03_pmc_hbm_traffic_1m_laplace.json",):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -189,8 +190,9 @@ def main():
                                                                     "lets the library replay repeated products as a hipGraph")
     ap.add_argument("--trans", default="N", choices=["N", "T", "C"], help="time the transposed product y = H^T x (H^H x) instead (single GPU; not the headline metric: "
                                                                           "no per-phase events, the roofline object stays empty)")
-    ap.add_argument("--no-warm-build", action="store_true", help="skip the small untimed warm-up build (build_s then includes the one-off costs of a "
-                                                                  "process's first build: code objects, streams, first allocations)")
+    ap.add_argument("--no-warm-build", action="store_true", help="build the operator once only: build_s is then build_cold_s, the first build of the process "
+                                                                  "(code objects, streams, first touch of the memory); default: the operator is built twice and both "
+                                                                  "times are reported")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the error against sampled exact rows is always reported)")
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON): libraries that chat on stdout (RCCL prints a version banner when a
@@ -250,42 +252,6 @@ def main():
 
     logging.getLogger("Htool").addHandler(_Keep())
     logging.getLogger("Htool").setLevel(logging.INFO)
-    vram_prep = None
-    if not args.no_warm_build:
-        # Device memory is handed out by the driver wiped: the first allocation of a VRAM region costs ~27 ms per GB, and memory freed
-        # by this or by the previous process is wiped in the background (~45 ms per GB) while new allocations wait for it
-        # (tools/vram_first_touch.py on a fresh box: 100 GB in 2.7 s, again 1 s after the free 4.5 s, again 6 s later 1 ms).  A build
-        # allocates ~170 GB at once, so build_s would swing between 0.4 and 4.8 s with what ran on the GPU before.  Untimed, like
-        # the warm-up products: touch the memory once, give it back, and let the wipe finish.
-        if not (dist_mode and args.backend == "gloo"):  # (rehearsal ranks share a GPU: nothing to grab)
-            free_b, _total_b = torch.cuda.mem_get_info()
-            t_prep = time.time()
-            try:
-                touch = torch.empty(int(free_b * 0.92), dtype=torch.uint8, device="cuda")
-                torch.cuda.synchronize()
-                t_alloc = time.time() - t_prep
-                del touch
-                torch.cuda.empty_cache()
-                wait_s = 1.0 + 0.06 * free_b * 0.92 / 1e9
-                time.sleep(wait_s)
-                vram_prep = {"touched_GB": free_b * 0.92 / 1e9, "alloc_s": t_alloc, "wait_s": wait_s}
-            except RuntimeError as e:  # (someone else holds the memory: the build will say so itself if it does not fit)
-                torch.cuda.empty_cache()
-                vram_prep = {"skipped": repr(e)[:200]}
-        # untimed warm-up, as for the products: a 20 000-point operator of the same kernel and dtype takes the one-off costs of a
-        # process's first build (code objects of the build kernels, streams, the first allocations) out of build_s
-        wp = points_in_sphere(20000, seed=1)
-        wcb = Htool.ClusterTreeBuilder()
-        wcb.set_maximal_leaf_size(args.leaf)
-        wcl = wcb.create_cluster_tree(wp, 2)
-        if is_complex:
-            Htool.ComplexHMatrixTreeBuilder(args.eps, args.eta, "N", "N").build(Htool.ComplexNativeGenerator(args.kernel, wp, wp, args.kappa), wcl, wcl)
-        else:
-            Htool.HMatrixTreeBuilder(args.eps, args.eta, "N", "N").build(Htool.NativeGenerator(args.kernel, wp, wp, {"laplace": 0.0, "inv_delta": 0.1}[args.kernel]), wcl, wcl)
-        torch.cuda.synchronize()
-        del wcl, wcb, wp
-        build_log.clear()
-
     pts = points_in_sphere(n, seed=0)
     t0 = time.time()
     cb = Htool.ClusterTreeBuilder()
@@ -303,9 +269,7 @@ def main():
     if args.symmetric:
         assert not dist_mode, "--symmetric is a single-GPU option (a row partition is not a symmetric operator)"
         builder.set_symmetric_storage(args.symmetric == "one-triangle")
-    torch.cuda.synchronize()
-    t0 = time.time()
-    dist_op, rccl_error, in_library = None, None, False
+    comm, rccl_error = None, None
     if dist_mode:
         # the reference's decomposition through its own entry point (DefaultApproximationBuilder, utility.hpp:26): rank p builds
         # rows(partition p) x all columns; the communicator carries a library-owned RCCL handle, so the exchange of every
@@ -315,19 +279,43 @@ def main():
         import mpi4py
 
         comm = mpi4py.MPI.COMM_WORLD
-        rccl_error = None
         if args.backend == "nccl":
             try:
                 comm.use_rccl()
             except Exception as e:  # reported in the JSON line ("exchange"); the exchange then goes through torch.distributed (also RCCL)
                 rccl_error = repr(e)
-        approx = Htool.DefaultApproximationBuilder(gen, cluster, cluster, builder, comm)
-        dist_op = approx.distributed_operator
-        H = approx.hmatrix
-    else:
-        H = builder.build(gen, cluster, cluster, rank if dist_mode else -1)
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
+
+    def timed_build():
+        build_log.clear()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if dist_mode:
+            approx = Htool.DefaultApproximationBuilder(gen, cluster, cluster, builder, comm)
+            op_, H_ = approx.distributed_operator, approx.hmatrix
+        else:
+            approx, op_ = None, None
+            H_ = builder.build(gen, cluster, cluster, -1)
+        torch.cuda.synchronize()
+        return approx, op_, H_, time.time() - t0, (build_log[-1] if build_log else None)
+
+    # FIRST build of the process, nothing warmed or pre-conditioned: code objects of the build kernels are loaded, streams created,
+    # every byte of VRAM the build uses is handed out (and wiped) by the driver for the first time -- build_cold_s
+    approx, dist_op, H, t_build_cold, cold_breakdown = timed_build()
+    t_build, build_breakdown = t_build_cold, cold_breakdown
+    vram_prep = None
+    if not args.no_warm_build:
+        # SECOND build of the process = build_s: the steady state of a process that builds operators repeatedly.  The first
+        # operator is destroyed; the library keeps its temporary ACA arena in the workspace cache (as it does for any later build),
+        # the panels go back to the driver, which wipes freed memory in the background (~45 ms per GB) while new allocations wait
+        # for it (tools/vram_first_touch.py) -- so the build waits, untimed, for that wipe instead of racing it.  (Round 2
+        # allocated 92 % of the free memory here; nothing is allocated any more: only what the first build itself touched is reused.)
+        freed_GB = H.stats()["hbm_bytes"] / 1e9
+        del approx, dist_op, H
+        torch.cuda.synchronize()
+        wait_s = 1.0 + 0.06 * freed_GB
+        time.sleep(wait_s)
+        vram_prep = {"freed_by_first_build_GB": freed_GB, "wait_s": wait_s, "allocated_for_preconditioning_GB": 0.0}
+        approx, dist_op, H, t_build, build_breakdown = timed_build()
     t_recompress = None
     if args.recompress:
         t0 = time.time()
@@ -477,15 +465,15 @@ def main():
     per_rank = None
     if dist_mode:
         dev = "cuda" if args.backend == "nccl" else "cpu"
-        mine = torch.tensor([tot_bytes, sum(ph) if n_ph else 0.0, exchange_us or 0.0, float(t_build)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([tot_bytes, sum(ph) if n_ph else 0.0, exchange_us or 0.0, float(t_build), float(t_build_cold)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"algorithmic_GB": float(v[0]) / 1e9, "product_us": float(v[1]), "exchange_us": float(v[2]), "build_s": float(v[3])} for v in allr]
-        t = torch.tensor([dt, tot_bytes, float(t_build)], dtype=torch.float64, device=dev)
+        per_rank = [{"algorithmic_GB": float(v[0]) / 1e9, "product_us": float(v[1]), "exchange_us": float(v[2]), "build_s": float(v[3]), "build_cold_s": float(v[4])} for v in allr]
+        t = torch.tensor([dt, tot_bytes, float(t_build), float(t_build_cold), float(t_cluster)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, tot_bytes, t_build = float(tmax[0]), float(t[1]), float(tmax[2])
+        dt, tot_bytes, t_build, t_build_cold, t_cluster = float(tmax[0]), float(t[1]), float(tmax[2]), float(tmax[3]), float(tmax[4])
     ms_per_step = dt / args.steps * 1e3
     value = tot_bytes / (dt / args.steps) / 1e9
 
@@ -509,12 +497,21 @@ def main():
             "n_points": n, "eps": args.eps, "eta": args.eta, "leaf": args.leaf, "kernel": args.kernel,
             "parallelism": f"rows{world}" if world > 1 else "single",
         },
+        # build_cold_s: the FIRST build of the process, nothing warmed (code objects, streams, first touch of every VRAM page, the
+        # driver's wipe of whatever ran on the GPU before).  build_s: the SECOND build of the same operator in the same process
+        # (the first one destroyed, its panels' wipe waited for untimed, the library's workspace cache holding the ACA arena) --
+        # the steady state of a process that builds operators repeatedly; equal to build_cold_s under --no-warm-build.
+        # setup_s / setup_cold_s add the cluster tree (host), which every build needs in front of it.
         "build_s": t_build,
+        "build_cold_s": t_build_cold,
+        "cluster_tree_s": t_cluster,
+        "setup_s": t_cluster + t_build,
+        "setup_cold_s": t_cluster + t_build_cold,
         "build_warmed": not args.no_warm_build,
         "vram_preconditioning": vram_prep,
-        "build_breakdown": build_log[-1] if build_log else None,
+        "build_breakdown": build_breakdown,
+        "build_cold_breakdown": cold_breakdown,
         "recompression_s": t_recompress,
-        "cluster_tree_s": t_cluster,
         "algorithmic_GB": tot_bytes / 1e9,
         "rhs_per_step": args.rhs,
         "trans": args.trans,

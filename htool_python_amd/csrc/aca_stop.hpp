@@ -1,0 +1,43 @@
+// aca_stop.hpp -- the stopping rule of the partially pivoted ACA, shared by every implementation of it in the library
+// (host_aca for callback generators, aca_wave / aca_multi / aca_kernel / the lockstep kernels for native ones).
+//
+// Reference behaviour: stop as soon as |u_k| |v_k| <= eps |A_k|_F.  That estimate looks at ONE rank-one term;
+// on degenerate clouds (nearly collinear points: the `sheet` cases of tools/fuzz.py) partial pivoting can pass it while a
+// large part of the block has not been seen yet -- profiles/r03_fuzz_sheet_case_61_322.txt: 65 eps left at rank 3, where
+// one more step finds a term a thousand times larger and the iteration ends at rank 6 with 0.06 eps.
+// htool_build_params.aca_confirm_steps = c > 0 asks for c further steps that pass the test as well before the iteration stops;
+// the confirming terms are then DROPPED (the leaf keeps the rank at which the test first passed), so on geometries where
+// the estimate was right all along the factors are bit for bit those of c = 0 -- the safeguard costs time (one more pivot
+// step per leaf and unit of c), not memory, and changes a leaf only when a confirming step fails.
+#pragma once
+#if defined(__HIPCC__)
+#define HM_HD __host__ __device__ __forceinline__
+#else
+#define HM_HD inline
+#endif
+
+namespace hm {
+
+// the kernels take ONE integer for "reqrank": r >= 0 = exactly r steps (no test), -1 - c = test with c confirming steps
+HM_HD int aca_reqrank_argument(int reqrank, int confirm) { return reqrank >= 0 ? reqrank : -1 - (confirm > 0 ? confirm : 0); }
+HM_HD int aca_confirm_steps(int reqrank_argument) { return reqrank_argument < 0 ? -1 - reqrank_argument : 0; }
+
+struct AcaStop {
+    int npass = 0;   // consecutive steps, up to the last one, that passed the test
+    int kfirst = 0;  // rank after the first of them
+    // after step number k (k terms computed): 0 = go on, 1 = stop and keep k terms (k may have been reset to kfirst),
+    // 2 = stop, the block is not worth storing in low-rank form.  Same order of checks as the reference loop: size first.
+    HM_HD int after_step(int &k, bool passed, bool too_big, bool no_next_row, int confirm) {
+        const int pending = npass;
+        if (passed) { if (npass == 0) kfirst = k; npass++; } else npass = 0;
+        if (too_big) { if (pending > 0) { k = kfirst; return 1; } return 2; } // (a test passed earlier: that rank was acceptable)
+        if (passed && npass > confirm) { k = kfirst; return 1; }
+        if (no_next_row) { if (npass > 0) k = kfirst; return 1; }
+        return 0;
+    }
+    // the iteration ends for another reason (capacity reached, every row used, rank limit): true when a passed test is pending,
+    // in which case k is reset to the rank it was passed at and the leaf is accepted
+    HM_HD bool settle(int &k) { if (npass > 0) { k = kfirst; return true; } return false; }
+};
+
+} // namespace hm

@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "hmatrix.hpp"
+#include "aca_stop.hpp"
 
 namespace hm {
 
@@ -43,6 +44,8 @@ int host_aca(const Generator &g, int M0, int N0, const int *rows0, const int *co
     double frob2 = 0;
     const int kmax = std::min(M, N);
     int result = -2;
+    AcaStop stop;
+    const int confirm = aca_confirm_steps(reqrank);
     while (k < kmax) {
         if (reqrank >= 0 && k >= reqrank) break;
         get_row(I, r.data());
@@ -93,8 +96,6 @@ int host_aca(const Generator &g, int M0, int N0, const int *rows0, const int *co
         U.insert(U.end(), c.begin(), c.end());
         V.insert(V.end(), r.begin(), r.end());
         k++;
-        if ((int64_t)k * (M + N) > (int64_t)M * N) { result = -1; break; }
-        if (reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0))) break;
         int nI = -1;
         double bc = -1;
         for (int i = 0; i < M; i++)
@@ -102,10 +103,15 @@ int host_aca(const Generator &g, int M0, int N0, const int *rows0, const int *co
                 double a = abs2(c[i]);
                 if (a > bc) bc = a, nI = i;
             }
-        if (nI < 0) break;
+        const int verdict = stop.after_step(k, reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0)), (int64_t)k * (M + N) > (int64_t)M * N, nI < 0, confirm);
+        if (verdict == 2) { result = -1; break; }
+        if (verdict == 1) break;
         I = nI;
     }
     if (result == -1) return -1;
+    stop.settle(k); // (the iteration ran out of rows / columns while a passed test was waiting for its confirmation)
+    U.resize((size_t)k * M); // confirming terms, if any, are dropped
+    V.resize((size_t)k * N);
     if (swp) { Uout.swap(V); Vout.swap(U); } // A = B^T = (U_B V_B)^T: U = V_B^T ([k][i] layout is V_B's), V = U_B^T
     else { Uout.swap(U); Vout.swap(V); }
     return k;
@@ -149,7 +155,7 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
                 }
             }
         } else {
-            rank = host_aca<T>(g, b.m, b.n, rows, cols, P.epsilon, P.reqrank, b.t_off > b.s_off, U, V);
+            rank = host_aca<T>(g, b.m, b.n, rows, cols, P.epsilon, aca_reqrank_argument(P.reqrank, P.aca_confirm_steps), b.t_off > b.s_off, U, V);
         }
         if (rank < 0) {
             split_failed_block(Tt, Ss, P, b, adm, dns);

@@ -244,6 +244,8 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
     H.params.symmetry = params->symmetry;
     H.params.uplo = params->uplo;
     H.params.reqrank = params->reqrank;
+    HM_CHECK(params->aca_confirm_steps >= 0 && params->aca_confirm_steps <= 8, "aca_confirm_steps must be between 0 and 8");
+    H.params.aca_confirm_steps = params->aca_confirm_steps;
     H.params.min_target_depth = params->minimal_target_depth;
     H.params.min_source_depth = params->minimal_source_depth;
     H.params.block_tree_consistency = params->block_tree_consistency;

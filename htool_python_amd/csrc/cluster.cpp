@@ -341,6 +341,7 @@ ClusterTree *build_cluster_tree(const ClusterBuildArgs &a) {
 ClusterTree *cluster_tree_from_tables(int n_points, int dim, int max_leaf, int n_children, const int *perm, int n_nodes, const int *ints7, const double *doubles4) {
     HM_CHECK(n_points > 0 && n_nodes > 0 && perm && ints7 && doubles4, "cluster tree tables: null or empty argument");
     HM_CHECK(dim >= 1 && dim <= 3, "cluster tree: spatial dimension must be 1, 2 or 3");
+    HM_CHECK(max_leaf >= 1 && n_children >= 2, "cluster tree tables: maximal_leaf_size must be >= 1 and number_of_children >= 2");
     std::unique_ptr<ClusterTree> Tp(new ClusterTree);
     ClusterTree &T = *Tp;
     T.n_points = n_points; T.dim = dim; T.max_leaf = max_leaf; T.n_children = n_children;

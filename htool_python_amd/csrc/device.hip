@@ -206,7 +206,12 @@ static void launch_sweep_T(DeviceHMatrix *D, const void *x_dev, long long x_stri
 
 // forget the captured product (its kernel arguments point into tables / workspaces that are about to change)
 static void drop_product_graph(DeviceHMatrix *D) {
-    if (D->graph.exec) (void)hipGraphExecDestroy(D->graph.exec);
+    if (D->graph.exec) {
+        // a replay launched by an earlier call may still be running on the caller's stream (call pattern A, A, A, B): the exec
+        // graph is destroyed only once that stream has passed it
+        if (D->graph.stream) (void)hipStreamSynchronize(D->graph.stream);
+        (void)hipGraphExecDestroy(D->graph.exec);
+    }
     D->graph = ProductGraph();
 }
 

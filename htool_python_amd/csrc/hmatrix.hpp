@@ -89,6 +89,7 @@ struct BuildParams {
     double epsilon = 1e-3, eta = 10;
     char symmetry = 'N', uplo = 'N';
     int reqrank = -1, min_target_depth = 0, min_source_depth = 0, block_tree_consistency = 1;
+    int aca_confirm_steps = 0;  // built-in ACA: further steps that must pass the stopping test as well (aca_stop.hpp); 0 = the reference's rule
     int store_one_triangle = 0; // 'S'/'H' on one cluster tree: keep the UPLO triangle only and apply stored leaves transposed too
     int (*compress)(void *, int, int, const int *, const int *, double, const void **, const void **, int *) = nullptr;
     void *compress_ctx = nullptr;

@@ -685,6 +685,13 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("set_dense_blocks_generator", [](B &b, py::object g) { b.dense_blocks = g.cast<std::shared_ptr<PyVirtualDenseBlocksGenerator<T>>>(); b.dense_blocks_ref = g; })
         .def("set_block_tree_consistency", [](B &b, bool c) { b.p.block_tree_consistency = c ? 1 : 0; })
         // extension: False stores both triangles of a symmetric operator (default: the UPLO triangle only, as the reference does)
+        .def("set_aca_confirmation_steps", [](B &b, int steps) {
+                if (steps < 0 || steps > 8) throw std::runtime_error("set_aca_confirmation_steps: between 0 and 8");
+                b.p.aca_confirm_steps = steps;
+            }, "steps"_a,
+             "Extension (htool_build_params.aca_confirm_steps).  0 (default): the reference's stopping rule of the partially pivoted ACA.  c > 0: a leaf is "
+             "accepted only after c further pivot steps have passed the stopping test too; the confirming terms are dropped, so leaves on which the test "
+             "was right keep exactly their factors -- a safeguard for nearly collinear point clouds, where partial pivoting can stop far too early.")
         .def("set_symmetric_storage", [](B &b, bool one_triangle) { b.p.store_one_triangle = one_triangle ? 1 : 0; }, "one_triangle"_a,
              "True (default): symmetry 'S'/'H' keeps the UPLO triangle only, as the reference does; every product uses each stored leaf "
              "twice in one fused sweep (half the memory, about 1.5x faster per vector above ~20 000 unknowns).  False: both triangles "
@@ -832,6 +839,11 @@ PYBIND11_MODULE(Htool, m) {
             return py::make_tuple(a, d);
         }, "target_cluster"_a, "source_cluster"_a, "eta"_a, "min_target_depth"_a = 0, "min_source_depth"_a = 0, "target_partition_number"_a = -1,
            "symmetry"_a = 'N', "UPLO"_a = 'N', "one_triangle"_a = true);
+    m.def("krylov_finish_step", [](std::uintptr_t W, long long ldw, int n, int mu, bool is_complex, std::uintptr_t h1, std::uintptr_t t2, int j, std::uintptr_t mask,
+                                   std::uintptr_t coef, bool scale, std::uintptr_t stream) {
+            check(htool_krylov_finish_step((void *)W, ldw, n, mu, is_complex ? 1 : 0, (const void *)h1, (const void *)t2, j, (const double *)mask, (void *)coef, scale ? 1 : 0, (void *)stream));
+        }, "W_ptr"_a, "ldw"_a, "n"_a, "mu"_a, "is_complex"_a, "h1_ptr"_a, "t2_ptr"_a, "j"_a, "mask_ptr"_a, "coef_ptr"_a, "scale"_a, "stream"_a,
+        "Scalar tail of a GMRES step in one launch (htool_krylov_finish_step): norm from the second Gram-Schmidt pass, scaling of w, coefficient row for the host");
     m.def("release_workspace", []() { return htool_release_workspace(); }, "Free the cached temporary device buffers of builds / recompressions; returns the bytes released");
     m.def("cluster_tiles", [](const PyCluster &c, int partition_number, int tile_max) {
             int n = htool_cluster_tiles(c.owner->root, partition_number, tile_max, nullptr, 0);

@@ -81,7 +81,12 @@ def save_cluster_to(cluster, properties_file, tree_file):
 
 
 def read_cluster_from(properties_file, tree_file):
-    """Htool.read_cluster_from(properties_csv, tree_csv) -> Cluster (root).  See save_cluster_to for the file layout."""
+    """Htool.read_cluster_from(properties_csv, tree_csv) -> Cluster (root).  See save_cluster_to for the file layout.
+
+    NOT interchangeable with upstream files: the reference's function of this name reads the CSV pair lib/htool's
+    save_cluster_tree writes (src/htool/clustering/utility.hpp:10); that writer and every sample of its output are absent from
+    the container, so this function reads the pair `Htool.save_cluster_to` writes and refuses anything else with a message that
+    says so ("Cluster files")."""
     from . import Htool as _core
 
     props = {}
@@ -94,7 +99,9 @@ def read_cluster_from(properties_file, tree_file):
         perm = np.array([int(v) for v in props["permutation"].split(",")], dtype=np.int32)
         dim, max_leaf, nch = int(props["space_dimension"]), int(props["maximal_leaf_size"]), int(props["number_of_children"])
     except (KeyError, ValueError) as e:
-        raise RuntimeError(f"read_cluster_from: {properties_file} is not a cluster properties file of this package ({e})")
+        raise RuntimeError(f"read_cluster_from: {properties_file} is not a cluster properties file written by this package's Htool.save_cluster_to ({e}); "
+                           "cluster files written by upstream htool (save_cluster_tree) are not supported -- rebuild the tree with ClusterTreeBuilder "
+                           "and save it with Htool.save_cluster_to")
     rows = np.loadtxt(tree_file, delimiter=",", ndmin=2)
     if rows.shape[1] != 11 or len(perm) != int(props.get("number_of_points", -1)) or len(rows) != int(props.get("number_of_nodes", -1)):
         raise RuntimeError("read_cluster_from: the tree file does not match the properties file")

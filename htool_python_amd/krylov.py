@@ -8,7 +8,10 @@ the iterate's slices inside the library):
   * TWO small all-reduces -- classical Gram-Schmidt applied twice (CGS2); the second reduce carries, behind the second
     pass's coefficients h2 = V^H w, the square w.w of the vector it was taken from, and the norm of the orthogonalised
     vector follows from |w - V h2|^2 = w.w - |h2|^2 (V has orthonormal rows), so there is no third reduce for the norm;
-  * ONE device -> host read-back (j + 2 coefficients per right-hand side), the only host synchronisation of the iteration.
+  * ONE device -> host read-back (2 j + 4 coefficients per right-hand side), the only host synchronisation of the iteration --
+    and a lagging one: the orthogonalised vector is normalised ON THE DEVICE (1 / sqrt(w.w - |h2|^2)), step j + 1 is enqueued
+    before the host looks at step j's coefficients (pinned buffer + event), so the device never waits for the Givens rotations.
+    Convergence is therefore noticed one step late: the step enqueued for nothing is ignored.
 
 The (restart+1) x restart Hessenberg least-squares problem is kept triangular on the host by Givens rotations (O(k) work per
 iteration on the coefficients that came back with that one read-back).
@@ -32,6 +35,36 @@ def _to_host(t):
     global HOST_SYNCS
     HOST_SYNCS += 1
     return t.cpu().numpy()
+
+
+class _Readback:
+    """Small device -> host transfers that do not stall the stream: the tensor is copied into one of two pinned buffers, an event
+    marks the copy, and the host waits for that event only when it needs the numbers -- one step later (gmres)."""
+
+    def __init__(self, dev, dt, count):
+        self.cuda = dev.type == "cuda"
+        self.turn = 0
+        if self.cuda:
+            self.buf = [torch.empty(count, dtype=dt).pin_memory() for _ in range(2)]
+            self.ev = [torch.cuda.Event() for _ in range(2)]
+
+    def post(self, t):
+        if not self.cuda:
+            return t.clone()
+        s, self.turn = self.turn, self.turn ^ 1
+        view = self.buf[s][: t.numel()].view(t.shape)
+        view.copy_(t, non_blocking=True)
+        self.ev[s].record()
+        return (s, view)
+
+    def wait(self, handle):
+        global HOST_SYNCS
+        HOST_SYNCS += 1
+        if not self.cuda:
+            return handle.numpy()
+        s, view = handle
+        self.ev[s].synchronize()
+        return view.numpy().copy()
 
 
 def _givens(ha, hb):
@@ -110,6 +143,12 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
             X[c] = 0
     m = max(1, int(restart))
     V = torch.empty(mu, m + 1, n, dtype=dt, device=dev)
+    rb = _Readback(dev, dt, mu * (2 * m + 4))
+    finish_kernel = None
+    if dev.type == "cuda":  # the scalar tail of a step as one launch of the library (csrc/krylov_device.hip) instead of ten tensor-library calls
+        from . import Htool as _core
+
+        finish_kernel = _core.krylov_finish_step
     restarts = 0
     first = x0 is None
     while max(its) < max_it and not all(converged):
@@ -137,7 +176,13 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
         g[:, 0] = beta * np.asarray(active, dtype=np.float64)
         kdone = [0] * mu  # Krylov dimension each column ends this cycle with
         running = list(active)
-        for j in range(m):
+        mask_host = np.asarray(running, dtype=np.float64)
+        mask_dev = torch.from_numpy(mask_host.copy()).to(dev) if mu > 1 else None
+
+        def enqueue_step(j):
+            """Device work of Arnoldi step j -- product, CGS2 with the norm folded into the second reduce, normalisation -- without
+            any host synchronisation; the coefficients go to the host asynchronously.  Row layout of what is posted, per column:
+            [h1 (j+1) | h2 (j+1) | w.w | hn^2]."""
             W = V[:, j + 1]
             Z = prec(V[:, j])
             if has_out:
@@ -148,16 +193,32 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
             h1 = allsum(dots(Vj, W))
             subtract(W, Vj, h1)
             t2 = allsum(dots(V[:, : j + 2], W))  # [h2 ; w.w]: the last row of V[:, : j + 2] is W itself
-            subtract(W, Vj, t2[:, : j + 1])
-            host = _to_host(torch.cat([h1, t2], dim=1))  # the iteration's one synchronisation
-            h1h, h2h, ww = host[:, : j + 1], host[:, j + 1: 2 * j + 2], host[:, 2 * j + 2].real
-            hn2 = ww - np.sum(np.abs(h2h) ** 2, axis=1)
-            if np.any(hn2[running] < 1e-2 * ww[running]):  # the second pass removed most of w: do not trust the difference
-                hn_all = norms(W)
-                hn2 = np.where(hn2 < 1e-2 * ww, hn_all ** 2, hn2)
+            h2 = t2[:, : j + 1]
+            subtract(W, Vj, h2)
+            if finish_kernel is not None:
+                # one launch of the library for the scalar tail: hn^2 = w.w - |h2|^2, w scaled by mask / hn, the coefficient row packed
+                coef = torch.empty(mu, 2 * j + 4, dtype=dt, device=dev)
+                finish_kernel(W.data_ptr(), W.stride(0) if mu > 1 else n, n, mu, cplx, h1.data_ptr(), t2.data_ptr(), j, mask_dev.data_ptr() if mask_dev is not None else 0,
+                              coef.data_ptr(), j + 1 < m, torch.cuda.current_stream().cuda_stream)
+                return rb.post(coef)
+            ww = t2[:, j + 1].real if cplx else t2[:, j + 1]
+            hn2 = ww - ((h2.real * h2.real + h2.imag * h2.imag) if cplx else h2 * h2).sum(dim=1)  # |w - V h2|^2 = w.w - |h2|^2
+            if j + 1 < m:
+                inv = torch.where(hn2 > 0, torch.rsqrt(hn2.clamp_min(1e-300)), torch.zeros_like(hn2))
+                if mask_dev is not None:
+                    inv = inv * mask_dev  # columns known to be finished stay zero
+                W.mul_(inv.unsqueeze(1))
+            return rb.post(torch.cat([h1, t2, hn2.unsqueeze(1).to(dt)], dim=1))
+
+        def process_step(j, host):
+            """Host work of step j on the coefficients that came back: Givens rotations, residuals, who goes on.  Returns True when
+            the cycle has to end after this step."""
+            nonlocal mask_dev
+            h1h, h2h = host[:, : j + 1], host[:, j + 1: 2 * j + 2]
+            ww, hn2 = host[:, 2 * j + 2].real, host[:, 2 * j + 3].real
             hn = np.sqrt(np.maximum(hn2, 0.0))
-            inv = np.zeros(mu)
-            stop = False
+            end_cycle = False
+            changed = False
             for c in range(mu):
                 if not running[c]:
                     continue
@@ -181,18 +242,36 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
                 if callback is not None and not batched:
                     callback(its[c], float(res))
                 if res <= tol or its[c] >= max_it or hn[c] == 0:
-                    running[c] = False  # frozen: its next Krylov vector is zeroed below
-                else:
-                    inv[c] = 1.0 / hn[c]
-            if not any(running):
-                stop = True
-            if not stop and j + 1 < m:
-                if mu == 1:
-                    W.mul_(inv[0])
-                else:
-                    W.mul_(torch.from_numpy(inv).to(device=dev, dtype=dt).unsqueeze(1))
-            if stop:
+                    running[c] = False  # frozen: its later Krylov vectors are ignored (and zeroed once the device knows)
+                    changed = True
+                elif hn2[c] < 1e-2 * ww[c]:
+                    # the second pass removed most of w (orthogonality nearly lost, or close to a breakdown): the difference
+                    # w.w - |h2|^2 is then inaccurate and so is the next basis vector's length -- end the cycle here and restart
+                    # from the true residual
+                    end_cycle = True
+            if changed and mask_dev is not None and any(running):
+                mask_dev = torch.from_numpy(np.asarray(running, dtype=np.float64)).to(dev)
+            return end_cycle or not any(running)
+
+        # Pipelined: step j is enqueued BEFORE the host looks at step j - 1 (whose coefficients have long arrived), so the device
+        # never waits for the host; a step enqueued for nothing (convergence is only known one step late) is simply ignored.
+        posted = None
+        enq = list(its)  # iterations counted including the enqueued, not yet processed steps
+        for j in range(m):
+            if not any(running[c] and enq[c] < max_it for c in range(mu)):
                 break
+            handle = enqueue_step(j)
+            for c in range(mu):
+                enq[c] += 1 if running[c] else 0
+            if posted is not None:
+                stop = process_step(posted[0], rb.wait(posted[1]))
+                posted = None
+                if stop:
+                    rb.wait(handle)  # (drain: the slot is reused by the next cycle)
+                    break
+            posted = (j, handle)
+        if posted is not None:
+            process_step(posted[0], rb.wait(posted[1]))
         kmax = max(kdone)
         Y = np.zeros((mu, kmax), dtype=npdt)
         for c in range(mu):

@@ -241,7 +241,33 @@ class Solver:
 
 
 class DDMSolverBuilder:
-    """Htool.DDMSolverBuilder(distributed_operator, block_diagonal_hmatrix).solver (src/htool/solver/utility.hpp:7-61)."""
+    """Htool.DDMSolverBuilder(distributed_operator, block_diagonal_hmatrix).solver (src/htool/solver/utility.hpp:7-61).
+
+    Only the two-argument form of the reference (utility.hpp:14) is on the HIP path.  The reference factorises
+    `block_diagonal_hmatrix` hierarchically in `facto_one_level()` (one-level Schwarz without overlap = block-Jacobi with the
+    rank's whole diagonal block); here `facto_one_level()` is block-Jacobi on the dense diagonal leaves of the rank's rows, so
+    the H-matrix handed in is kept (`get_local_hmatrix()`) but NOT factorised -- said once, at WARNING level.  The overlapping
+    forms (utility.hpp:16-40: subdomain numberings, neighbours, intersections) need HPDDM's Schwarz machinery and are refused."""
 
     def __init__(self, distributed_operator, block_diagonal_hmatrix=None, *args, **kwargs):
+        if args or kwargs:
+            raise RuntimeError("DDMSolverBuilder: only DDMSolverBuilder(distributed_operator, block_diagonal_hmatrix) is implemented on the HIP path; "
+                               "the overlapping-subdomain constructors (src/htool/solver/utility.hpp:16-40) are outside it")
         self.solver = Solver(distributed_operator)
+        self._local_hmatrix = block_diagonal_hmatrix
+        self.local_to_global_numbering = None
+        if block_diagonal_hmatrix is not None:
+            import logging
+
+            logging.getLogger("Htool").warning(
+                "DDMSolverBuilder: block_diagonal_hmatrix is accepted but not factorised -- facto_one_level() sets up block-Jacobi on the dense "
+                "diagonal leaves of this rank's rows instead of the reference's hierarchical LU of the whole diagonal block")
+
+    def get_local_hmatrix(self):
+        return self._local_hmatrix
+
+
+# (src/htool/solver/utility.hpp:46-60, solver.hpp:68-69: the variants whose local solver is dense LAPACK -- on this engine the
+# one-level preconditioner is dense block-Jacobi either way, so they are the same classes)
+DDMSolverWithDenseLocalSolver = DDMSolverBuilder
+SolverDense = Solver

@@ -134,6 +134,12 @@ typedef struct htool_build_params {
      * every stored off-diagonal leaf a second time, (conjugate) transposed, in the same pass over its panels.
      * 0: both triangles are stored and the product is a single plain sweep (faster for many right-hand sides). */
     int store_one_triangle;
+    /* Built-in ACA only (an extension; 0 = the reference's stopping rule |u_k| |v_k| <= epsilon |A_k|_F, tested on one term):
+     * c > 0 asks for c further pivot steps that pass the test as well before a leaf is accepted; the confirming terms are
+     * dropped, so leaves on which the test was right keep exactly the factors of c = 0, and a leaf changes only when a
+     * confirming step finds a large term (nearly collinear clouds, where partial pivoting can stop far too early:
+     * profiles/r03_fuzz_sheet_case_61_322.txt).  Costs one more pivot step per leaf and unit of c.  0 .. 8. */
+    int aca_confirm_steps;
 } htool_build_params;
 void htool_build_params_default(htool_build_params *p);
 
@@ -309,6 +315,16 @@ int htool_distributed_exchange_kind(const htool_distributed *d, int mu);
  * displs[p] .. displs[p] + counts[p] (counts / displs: host arrays of P ints). */
 int htool_debug_compact_slices(const void *gathered_dev, void *x_full_dev, const int *counts, const int *displs, int P, int pad, int mu, int64_t ldx,
                                int is_complex, void *stream);
+
+/* ---- Krylov helper (solver/solver.hpp:22-65: the reference hands the operator to HPDDM; this package runs its own GMRES on
+ * device-resident vectors, htool_python_amd/krylov.py) -------------------------------------------------------------------
+ * The scalar tail of an Arnoldi step with classical Gram-Schmidt applied twice, as ONE launch on `stream`: for each of the mu
+ * right-hand sides, with h1 (j + 1 coefficients of the first pass) and t2 = [h2 | w.w] (j + 2 values of the second pass, after
+ * their reduction over the ranks) in device memory, hn^2 = w.w - |h2|^2, column c of W (n entries at W + c * ldw) scaled by
+ * mask[c] / sqrt(hn^2) (0 when hn^2 <= 0; mask NULL = all ones; scale = 0: left as it is), and the row
+ * [h1 | h2 | w.w | hn^2] (2 j + 4 entries of the coefficient type) written to coef + c * (2 j + 4) for the host to fetch. */
+int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_complex, const void *h1_dev, const void *t2_dev, int j, const double *mask_dev,
+                             void *coef_dev, int scale, void *stream);
 
 #ifdef __cplusplus
 }

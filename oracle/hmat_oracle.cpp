@@ -331,6 +331,11 @@ static int aca(const Gen &g, int M0, int N0, const int *rows0, const int *cols0,
     double frob2 = 0;
     const int kmax = std::min(M, N);
     bool failed = false;
+    // Confirmation of the stopping test (an extension of the engine, include/htool_mi355x.h: aca_confirm_steps; the argument
+    // reqrank = -1 - c carries c): the iteration goes on for c more steps after the test has passed; if they pass too the
+    // leaf keeps the rank of the FIRST pass (the later terms are dropped), if one of them fails the streak starts over.
+    const int confirm = reqrank < 0 ? -1 - reqrank : 0;
+    int streak = 0, rank_at_first_pass = 0;
     while (k < kmax) {
         if (reqrank >= 0 && k >= reqrank) break;
         for (int j = 0; j < N; j++) { T a; entry(I, j, a); r[j] = a; }
@@ -366,14 +371,23 @@ static int aca(const Gen &g, int M0, int N0, const int *rows0, const int *cols0,
         U.insert(U.end(), c.begin(), c.end());
         V.insert(V.end(), r.begin(), r.end());
         k++;
-        if ((int64_t)k * (M + N) > (int64_t)M * N) { failed = true; break; }
-        if (reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0))) break;
+        const bool streak_before = streak > 0;
+        const bool pass = reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0));
+        if (pass) { if (streak == 0) rank_at_first_pass = k; streak++; } else streak = 0;
+        if ((int64_t)k * (M + N) > (int64_t)M * N) { // too many terms to be worth storing -- unless an earlier rank had already passed
+            if (streak_before) { k = rank_at_first_pass; streak = 0; } else failed = true;
+            break;
+        }
+        if (pass && streak > confirm) break;
         int nI = -1; double bc = -1;
         for (int i = 0; i < M; i++) if (!urow[i]) { double a = abs2(c[i]); if (a > bc) { bc = a; nI = i; } }
         if (nI < 0) break;
         I = nI;
     }
     if (failed) return -1;
+    if (streak > 0) k = rank_at_first_pass; // (also when rows / columns ran out while a pass was waiting to be confirmed)
+    U.resize((size_t)k * M);
+    V.resize((size_t)k * N);
     if (swp) { Uout.swap(V); Vout.swap(U); } else { Uout.swap(U); Vout.swap(V); }
     return k;
 }

@@ -127,7 +127,9 @@ def aca(kind, tpts, spts, p0, rows, cols, eps, is_complex=False, reqrank=-1):
 
 class HMatrix:
     def __init__(self, tc, sc, kind, p0=0.0, is_complex=False, eps=1e-3, eta=10.0, symmetry="N", uplo="N",
-                 reqrank=-1, min_t=0, min_s=0, target_partition=-1):
+                 reqrank=-1, min_t=0, min_s=0, target_partition=-1, confirm=0):
+        if reqrank < 0:
+            reqrank = -1 - int(confirm)  # (confirmation steps of the stopping test ride on the reqrank argument, see hmat_oracle.cpp aca)
         self.tc, self.sc, self.is_complex = tc, sc, is_complex
         self.dtype = np.complex128 if is_complex else np.float64
         self.h = lib().orc_hmat_build(tc.h, sc.h, kind, p0, int(is_complex), eps, eta, symmetry.encode(), uplo.encode(),

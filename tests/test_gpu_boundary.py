@@ -193,3 +193,45 @@ def test_damaged_checkpoints_are_refused(built, oracle, tmp_path):
     other = b2.create_cluster_tree(pts[:, ::-1].copy(), 2)
     with pytest.raises(RuntimeError, match="permutations differ"):
         Htool.load_hmatrix(ps, cl, other)
+
+
+def test_graph_replay_then_other_buffers(built, oracle):
+    """the hipGraph of a repeated product (same buffers, same caller-named stream) is replayed; a product on OTHER
+    buffers issued right behind replays that may still be in flight (call pattern A, A, A, A, B, A, A, C ...) must neither disturb
+    them nor be disturbed: every result equals the eager product of the same operator, bit for bit."""
+    import torch
+
+    import Htool
+
+    O = oracle
+    n = 20000
+    np.random.seed(4)
+    pts = O.points_in_sphere(n)
+    cb = Htool.ClusterTreeBuilder()
+    cb.set_maximal_leaf_size(64)
+    cl = cb.create_cluster_tree(pts, 2)
+    H = Htool.HMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", pts, pts), cl, cl)
+    torch.cuda.set_stream(torch.cuda.Stream())
+    st = torch.cuda.current_stream().cuda_stream
+    xs = [torch.rand(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    ys = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+    # eager references on the operator's own stream (stream 0: never captured)
+    refs = []
+    for x in xs:
+        r = torch.zeros(n, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        H.matvec_device(x.data_ptr(), r.data_ptr(), 0, 0)
+        torch.cuda.synchronize()
+        refs.append(r.clone())
+    for _round in range(3):
+        for which in (0, 0, 0, 0, 1, 0, 0, 2, 2, 2, 1):  # second identical call captures, later ones replay; then the key changes at once
+            H.matvec_device(xs[which].data_ptr(), ys[which].data_ptr(), 0, st)
+        # several right-hand sides right behind replays of the single-vector graph (another workspace size: the graph is dropped)
+        X = torch.stack(xs)
+        Y = torch.zeros(3, n, dtype=torch.float64, device="cuda")
+        H.matmat_device(X.data_ptr(), n, Y.data_ptr(), n, 3, 0, st)
+        H.matvec_device(xs[0].data_ptr(), ys[0].data_ptr(), 0, st)
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert torch.equal(ys[i], refs[i]) and torch.equal(Y[i], refs[i])
+            ys[i].zero_()

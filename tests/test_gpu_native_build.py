@@ -653,3 +653,154 @@ def test_more_work_items_than_one_launch_can_hold(built, oracle):
     ye = exact_rows("laplace", pt, ps, x, 0.0, rows)
     assert np.linalg.norm(y[rows] - ye) / np.linalg.norm(ye) < eps
     Htool.release_workspace()
+
+
+@pytest.mark.parametrize("case", ["laplace", "inv_delta_eta2", "helmholtz", "high_accuracy", "reqrank", "rectangular"])
+def test_lockstep_aca_of_the_largest_leaves(built, oracle, monkeypatch, case):
+    """The lockstep ACA (csrc/device_aca_steps.inc: every phase of a pivot step one grid-wide launch over all leaves of the
+    class) is meant for leaves of more than 8192 rows or columns; HTOOL_ACA_STEP_MIN sends ordinary leaves down that path so
+    that it is compared, leaf by leaf, with the CPU ACA (ranks equal on >= 99 %, +-1 otherwise), with the build that uses the
+    workgroup kernel (same ranks but for borderline leaves, factors equal to 1e-12 where the ranks agree) and with the exact
+    operator.  `high_accuracy` makes leaves exceed their capacity and fail (retry / re-split), `reqrank` fixes the step count,
+    chunks of 1024: leaves of 1200-2400 rows have two or three chunks per phase."""
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    np.random.seed(0)
+    cplx = case == "helmholtz"
+    n, leaf, eta, eps, kind, p0, reqrank = {"laplace": (20000, 100, 10.0, 1e-4, 1, 0.0, -1), "inv_delta_eta2": (9000, 64, 2.0, 1e-6, 0, 0.1, -1),
+                                            "helmholtz": (12000, 64, 10.0, 1e-4, 2, 6.0, -1), "high_accuracy": (6000, 16, 10.0, 1e-11, 1, 0.0, -1),
+                                            "reqrank": (8000, 64, 10.0, 1e-3, 1, 0.0, 6), "rectangular": (9000, 50, 10.0, 1e-5, 0, 0.1, -1)}[case]
+    pts = O.points_in_sphere(n)
+    pts_s = O.points_in_sphere(n // 2 + 77) + 0.3 if case == "rectangular" else pts
+    name = {0: "inv_delta", 1: "laplace", 2: "helmholtz"}[kind]
+
+    def build():
+        tcl = cluster_of(pts, leaf)
+        scl = tcl if pts_s is pts else cluster_of(pts_s, leaf)
+        if cplx:
+            return Htool.ComplexHMatrixTreeBuilder(eps, eta, "N", "N", reqrank=reqrank).build(Htool.ComplexNativeGenerator(name, pts, pts_s, p0), tcl, scl), tcl, scl
+        return Htool.HMatrixTreeBuilder(eps, eta, "N", "N", reqrank=reqrank).build(Htool.NativeGenerator(name, pts, pts_s, p0), tcl, scl), tcl, scl
+
+    monkeypatch.setenv("HTOOL_ACA_STEP_MIN", "0")      # never
+    H0, _, _ = build()
+    smin = 120 if case == "inv_delta_eta2" else 300    # (eta = 2: few large admissible leaves)
+    monkeypatch.setenv("HTOOL_ACA_STEP_MIN", str(smin))  # every leaf of more than that many rows or columns
+    H1, tcl, scl = build()
+    L0, L1 = np.asarray(H0.leaves()), np.asarray(H1.leaves())
+    a, b = {tuple(l[:4]): int(l[4]) for l in L0}, {tuple(l[:4]): int(l[4]) for l in L1}
+    assert set(a) == set(b)
+    big = [k for k in a if max(k[1], k[3]) > smin and a[k] >= 0]
+    assert len(big) >= 8, len(big)                        # the path was really taken
+    d = np.array([a[k] - b[k] for k in big])
+    assert np.mean(d != 0) <= 0.02 and np.abs(d).max() <= 1, (np.mean(d != 0), np.abs(d).max())
+    if reqrank >= 0:
+        assert {b[k] for k in big} == {reqrank}
+    # factors: where the ranks agree, U V of the two builds agree (same pivots, other summation order)
+    idx1 = {tuple(l[:4]): i for i, l in enumerate(L1)}
+    idx0 = {tuple(l[:4]): i for i, l in enumerate(L0)}
+    rng = np.random.RandomState(1)
+    same = [k for k in big if a[k] == b[k] and a[k] > 0]
+    for k in [same[i] for i in rng.choice(len(same), size=min(25, len(same)), replace=False)]:
+        U0, V0 = H0.leaf_panels(idx0[k])
+        U1, V1 = H1.leaf_panels(idx1[k])
+        B0, B1 = np.asarray(U0) @ np.asarray(V0), np.asarray(U1) @ np.asarray(V1)
+        assert np.linalg.norm(B0 - B1) <= 1e-9 * np.linalg.norm(B0), (k, np.linalg.norm(B0 - B1) / np.linalg.norm(B0))
+    # against the CPU ACA (oracle) and the exact operator
+    if case in ("laplace", "helmholtz", "inv_delta_eta2"):
+        oc = O.Cluster(pts, max_leaf=leaf)
+        OH = O.HMatrix(oc, oc, kind, p0, is_complex=cplx, eps=eps, eta=eta)
+        theirs = {tuple(l[:4]): int(l[4]) for l in OH.leaves}
+        assert set(theirs) == set(b)
+        dd = np.array([b[k] - theirs[k] for k in big])
+        assert np.mean(dd != 0) < 0.02 and np.abs(dd).max() <= 1
+    x = rng.rand(pts_s.shape[1]) + (1j * rng.rand(pts_s.shape[1]) if cplx else 0)
+    rows = np.arange(0, n, 7)
+    ye = O.dense_matvec(kind, pts, pts_s, x, p0, rows=rows)
+    if reqrank < 0:
+        assert np.linalg.norm((H1 * x)[rows] - ye) / np.linalg.norm(ye) < eps
+    assert np.linalg.norm(H1 * x - H0 * x) / np.linalg.norm(H0 * x) < (1e-2 if reqrank >= 0 else 2 * eps)
+
+
+def test_aca_confirmation_steps(built, oracle):
+    """htool_build_params.aca_confirm_steps / HMatrixTreeBuilder.set_aca_confirmation_steps (an extension, default 0 = the
+    reference's stopping rule).  VERDICT round 2, weak spot 5a: on nearly collinear clouds (`shape = sheet` of tools/fuzz.py) the
+    partially pivoted ACA passes its stopping test far too early -- shown with the independent explicit-residual ACA in
+    profiles/r03_fuzz_sheet_case_61_322.txt -- and one confirming step repairs it.
+    (1) sheet cloud: error of the product 40-60 epsilon without, < epsilon with one confirming step; ranks as the CPU oracle's.
+    (2) ball (the reference's geometry): leaves whose rank is unchanged keep their factors BIT FOR BIT (the confirming terms are
+        dropped); the others gained terms because a confirming step failed; storage grows by a few per cent, the error shrinks.
+    (3) the callback-generator path (host ACA) follows the same rule; out-of-range values are refused."""
+    import Htool
+    from tests.helpers import NumpyGenerator, cluster_of
+
+    O = oracle
+
+    def build(pt, ps, kind, p0, eps, eta, leaf, confirm, strategy=None):
+        cb = Htool.ClusterTreeBuilder()
+        cb.set_maximal_leaf_size(leaf)
+        if strategy is not None:
+            cb.set_partitioning_strategy(strategy)
+        tcl = cb.create_cluster_tree(pt, 2)
+        scl = tcl if ps is pt else cb.create_cluster_tree(ps, 2)
+        b = Htool.HMatrixTreeBuilder(eps, eta, "N", "N")
+        b.set_aca_confirmation_steps(confirm)
+        return b.build(Htool.NativeGenerator({0: "inv_delta", 1: "laplace"}[kind], pt, ps, p0), tcl, scl)
+
+    def ranks(H):
+        return {tuple(l[:4]): int(l[4]) for l in np.asarray(H.leaves() if hasattr(H, "leaves") and callable(H.leaves) else H.leaves)}
+
+    # (1) sheet
+    rng = np.random.RandomState(4)
+    n = 40000
+    pt = np.asfortranarray(rng.rand(2, n)); pt[-1] *= 1e-3
+    ns = int(n * 0.55)
+    ps = np.asfortranarray(rng.rand(2, ns)); ps[-1] *= 1e-3
+    x = rng.rand(ns)
+    rows = np.arange(0, n, 97)
+    eps = 4e-6
+    ye = O.dense_matvec(0, pt, ps, x, 0.1, rows=rows)
+    errs = []
+    for confirm in (0, 1):
+        H = build(pt, ps, 0, 0.1, eps, 10.0, 33, confirm)
+        errs.append(np.linalg.norm((H * x)[rows] - ye) / np.linalg.norm(ye) / eps)
+        oc, ocs = O.Cluster(pt, max_leaf=33), O.Cluster(ps, max_leaf=33)
+        OH = O.HMatrix(oc, ocs, 0, 0.1, eps=eps, eta=10.0, confirm=confirm)
+        a, b = ranks(H), {tuple(l[:4]): int(l[4]) for l in OH.leaves}
+        assert set(a) == set(b)
+        d = np.array([a[k] - b[k] for k in a])
+        assert np.mean(d != 0) < 0.02 and np.abs(d).max() <= 2, (confirm, np.mean(d != 0), np.abs(d).max())
+    assert errs[0] > 10 and errs[1] < 1.0, errs
+    # (2) ball
+    np.random.seed(0)
+    pts = O.points_in_sphere(20000)
+    H0, H1 = build(pts, pts, 1, 0.0, 1e-4, 10.0, 64, 0), build(pts, pts, 1, 0.0, 1e-4, 10.0, 64, 1)
+    L0, L1 = np.asarray(H0.leaves()), np.asarray(H1.leaves())
+    assert np.array_equal(L0[:, :4], L1[:, :4])
+    adm = L0[:, 4] >= 0
+    grew = L1[adm, 4] - L0[adm, 4]
+    assert grew.min() >= 0 and 0.02 < np.mean(grew > 0) < 0.4          # a confirming step failed on some leaves: they went on
+    stored = lambda L: float((L[adm, 4] * (L[adm, 1] + L[adm, 3])).sum())  # noqa: E731
+    assert 1.0 < stored(L1) / stored(L0) < 1.1
+    same = np.flatnonzero(adm & (L0[:, 4] == L1[:, 4]) & (L0[:, 4] > 0))
+    for i in np.random.RandomState(2).choice(same, size=40, replace=False):
+        (U0, V0), (U1, V1) = H0.leaf_panels(int(i)), H1.leaf_panels(int(i))
+        assert np.array_equal(np.asarray(U0), np.asarray(U1)) and np.array_equal(np.asarray(V0), np.asarray(V1))
+    xb = np.random.rand(20000)
+    rb = np.arange(0, 20000, 53)
+    yb = O.dense_matvec(1, pts, pts, xb, 0.0, rows=rb)
+    e0, e1 = (np.linalg.norm((H * xb)[rb] - yb) / np.linalg.norm(yb) for H in (H0, H1))
+    assert e1 <= e0 * 1.05 and e0 < 1e-4
+    # (3) callback generator: the host ACA applies the same rule (ranks of the CPU oracle with the same setting)
+    np.random.seed(1)
+    ph = O.points_in_sphere(1500)
+    cl = cluster_of(ph, 20)
+    for confirm in (0, 2):
+        b = Htool.HMatrixTreeBuilder(1e-5, 10.0, "N", "N")
+        b.set_aca_confirmation_steps(confirm)
+        Hh = b.build(NumpyGenerator(ph, ph), cl, cl)
+        OH = O.HMatrix(O.Cluster(ph, max_leaf=20), O.Cluster(ph, max_leaf=20), O.K_INV_DELTA, 0.1, eps=1e-5, eta=10.0, confirm=confirm)
+        assert ranks(Hh) == {tuple(l[:4]): int(l[4]) for l in OH.leaves}
+    with pytest.raises(RuntimeError):
+        Htool.HMatrixTreeBuilder(1e-3, 10.0, "N", "N").set_aca_confirmation_steps(9)

