@@ -21,8 +21,8 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 
 HOST_SOURCES = ["util.cpp", "cluster.cpp", "blocktree.cpp", "layout.cpp", "build_host.cpp", "capi.cpp"]
-HIP_SOURCES = ["device.hip", "dist_device.hip", "krylov_device.hip"]
-HEADERS = ["common.hpp", "cluster.hpp", "hmatrix.hpp", "device_internal.hpp", "capi_internal.hpp", "device_build.inc", "device_aca_wave.inc", "device_aca_steps.inc", "device_recompress.inc", "product_kernels.inc", "product_mfma.inc", "pack_kernels.inc", "device_memory.inc",
+HIP_SOURCES = ["device.hip", "dist_device.hip", "krylov_device.hip", "dense_device.hip"]
+HEADERS = ["common.hpp", "cluster.hpp", "hmatrix.hpp", "device_internal.hpp", "capi_internal.hpp", "device_build.inc", "device_aca_wave.inc", "device_aca_steps.inc", "aca_stop.hpp", "device_recompress.inc", "product_kernels.inc", "product_mfma.inc", "pack_kernels.inc", "device_memory.inc",
            "device_tables.inc", os.path.join("..", "..", "include", "htool_mi355x.h")]
 
 
@@ -58,7 +58,7 @@ def build(force=False):
             _run([HIPCC, "--offload-arch=" + ARCH, "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-result", "-c", src, "-o", obj])
         objs.append(obj)
     if force or _newer(LIB, objs):
-        _run(["g++", "-shared", "-o", LIB] + objs + ["-fopenmp", "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+        _run(["g++", "-shared", "-o", LIB] + objs + ["-fopenmp", "-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-lrccl", "-ldl", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     ext = ext_path()
     pysrc = os.path.join(SRC, "pyhtool.cpp")
     if force or _newer(ext, [pysrc, LIB, os.path.join(HERE, "..", "include", "htool_mi355x.h")]):

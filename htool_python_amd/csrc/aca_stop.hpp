@@ -23,21 +23,31 @@ HM_HD int aca_reqrank_argument(int reqrank, int confirm) { return reqrank >= 0 ?
 HM_HD int aca_confirm_steps(int reqrank_argument) { return reqrank_argument < 0 ? -1 - reqrank_argument : 0; }
 
 struct AcaStop {
-    int npass = 0;   // consecutive steps, up to the last one, that passed the test
-    int kfirst = 0;  // rank after the first of them
-    // after step number k (k terms computed): 0 = go on, 1 = stop and keep k terms (k may have been reset to kfirst),
-    // 2 = stop, the block is not worth storing in low-rank form.  Same order of checks as the reference loop: size first.
+    // ONE integer of state (the register ACA kernels run at their register limit): bits 20.. = consecutive steps, up to the
+    // last one, that passed the test; bits 0..19 = the rank after the first of them.  0 = no passed test pending.
+    int st = 0;
+    // after step number k (k terms computed): 0 = go on, 1 = stop and keep k terms (k may have been reset to the rank of the
+    // first pass), 2 = stop, the block is not worth storing in low-rank form.  Same order of checks as the reference loop: size first.
     HM_HD int after_step(int &k, bool passed, bool too_big, bool no_next_row, int confirm) {
-        const int pending = npass;
-        if (passed) { if (npass == 0) kfirst = k; npass++; } else npass = 0;
-        if (too_big) { if (pending > 0) { k = kfirst; return 1; } return 2; } // (a test passed earlier: that rank was acceptable)
-        if (passed && npass > confirm) { k = kfirst; return 1; }
-        if (no_next_row) { if (npass > 0) k = kfirst; return 1; }
+#ifdef HTOOL_ACA_NO_CONFIRM // (A/B builds: the reference's rule only, no state)
+        (void)confirm;
+        if (too_big) return 2;
+        return (passed || no_next_row) ? 1 : 0;
+#else
+        const int before = st;
+        st = passed ? (before != 0 ? before + (1 << 20) : (k | (1 << 20))) : 0;
+        if (too_big) { if (before != 0) { k = before & 0xfffff; return 1; } return 2; } // (a test passed earlier: that rank was acceptable)
+        if (passed && (st >> 20) > confirm) { k = st & 0xfffff; return 1; }
+        if (no_next_row) { if (st != 0) k = st & 0xfffff; return 1; }
         return 0;
+#endif
     }
     // the iteration ends for another reason (capacity reached, every row used, rank limit): true when a passed test is pending,
     // in which case k is reset to the rank it was passed at and the leaf is accepted
-    HM_HD bool settle(int &k) { if (npass > 0) { k = kfirst; return true; } return false; }
+    HM_HD bool settle(int &k) {
+        if (st != 0) { k = st & 0xfffff; return true; }
+        return false;
+    }
 };
 
 } // namespace hm

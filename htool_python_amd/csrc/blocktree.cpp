@@ -93,6 +93,8 @@ void visit(const Ctx &c, int t, int s) {
 // node pairs -> leaf records appended to out (all threads)
 void materialise(const ClusterTree &T, const ClusterTree &S, const std::vector<NodePair> &ids, std::vector<BlockRec> &out) {
     const size_t base = out.size();
+    // (room for the leaves a build appends later -- retried, re-split ones -- without moving 75 MB of records at 1 M points)
+    out.reserve(base + ids.size() + ids.size() / 8 + 4096);
     out.resize(base + ids.size());
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)ids.size(); i++) out[base + i] = make_block(T, S, ids[i].first, ids[i].second);

@@ -562,6 +562,16 @@ int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering
     API_END
 }
 
+// Where a factorisation runs.  Whole-cluster operators of at most 20 000 unknowns: the host fallback below (round 1).  Larger
+// ones and partition-built blocks (the block_diagonal_hmatrix of a distributed operator, in its local numbering): a dense copy on
+// the device factorised by the dense solver library (dense_device.hip).  HTOOL_DENSE_FACTOR=device / host forces one (tests).
+static bool factor_on_device(const HMatrix &H) {
+    if (const char *v = getenv("HTOOL_DENSE_FACTOR")) {
+        if (std::string(v) == "device") return true;
+        if (std::string(v) == "host") return false;
+    }
+    return H.t_root != 0 || H.s_root != 0 || H.local_numbering || H.tc->n_points > 20000;
+}
 static DenseFactor *factor_of(htool_hmatrix *h, int kind, char uplo) {
     const HMatrix &H = h->H;
     HM_CHECK(H.t_root == 0 && H.tc->n_points == H.sc->n_points, "factorization needs a square H-matrix built on the whole clusters");
@@ -574,24 +584,63 @@ static DenseFactor *factor_of(htool_hmatrix *h, int kind, char uplo) {
     else { f->ar.resize((size_t)n * n); densify(H, f->ar.data(), 1); if (kind == 1) lu_factor(n, f->ar, f->piv); else chol_factor(n, f->ar, uplo); }
     return f.release();
 }
-int htool_hmatrix_lu_factorization(htool_hmatrix *h) {
-    API_BEGIN
-    DenseFactor *f = factor_of(h, 1, 'N');
+static void factorise(htool_hmatrix *h, int kind, char uplo, double shift) {
+    if (factor_on_device(h->H)) {
+        log_message(LOG_WARNING, strprintf("%s: dense fallback on the device (a dense copy of the operator is factorised by the dense solver library; hierarchical LU is not part of this engine)",
+                                           kind == 1 ? "lu_factorization" : "cholesky_factorization"));
+        DeviceDenseFactor *f = device_dense_factor(h->H, kind, uplo, shift);
+        device_dense_factor_free(h->dfactor);
+        h->dfactor = f;
+        delete (DenseFactor *)h->factor;
+        h->factor = nullptr;
+        return;
+    }
+    HM_CHECK(shift == 0.0, "factorization with a diagonal shift is implemented on the device path only");
+    DenseFactor *f = factor_of(h, kind, uplo);
     delete (DenseFactor *)h->factor;
     h->factor = f;
+    device_dense_factor_free(h->dfactor);
+    h->dfactor = nullptr;
+}
+int htool_hmatrix_lu_factorization(htool_hmatrix *h) {
+    API_BEGIN
+    factorise(h, 1, 'N', 0.0);
+    API_END
+}
+int htool_hmatrix_lu_factorization_shifted(htool_hmatrix *h, double shift) {
+    API_BEGIN
+    HM_CHECK(factor_on_device(h->H), "lu_factorization_shifted: device path only (operators beyond 20000 unknowns, partition-built blocks, or HTOOL_DENSE_FACTOR=device)");
+    factorise(h, 1, 'N', shift);
     API_END
 }
 int htool_hmatrix_cholesky_factorization(htool_hmatrix *h, char uplo) {
     API_BEGIN
     HM_CHECK(uplo == 'L' || uplo == 'U', "UPLO must be 'L' or 'U'");
-    HM_CHECK(!h->H.is_complex, "cholesky_factorization: complex operators are not supported by the dense host fallback");
-    DenseFactor *f = factor_of(h, 2, uplo);
-    delete (DenseFactor *)h->factor;
-    h->factor = f;
+    HM_CHECK(!h->H.is_complex, "cholesky_factorization: complex operators are not supported by the dense fallback");
+    factorise(h, 2, uplo, 0.0);
+    API_END
+}
+int htool_hmatrix_factor_solve_device(const htool_hmatrix *h, int kind, char trans, void *B_dev, int64_t ldb, int mu, void *stream) {
+    API_BEGIN
+    HM_CHECK(h->dfactor != nullptr && device_dense_factor_kind(h->dfactor) == kind, "factor_solve_device: no device factorisation of that kind (call lu_factorization / cholesky_factorization first; "
+                                                                                     "operators of at most 20000 unknowns are factorised on the host unless HTOOL_DENSE_FACTOR=device)");
+    device_dense_solve(h->dfactor, trans, B_dev, (long long)ldb, mu, stream ? stream : (void *)nullptr);
+    API_END
+}
+int htool_hmatrix_to_dense_device(const htool_hmatrix *h, void *out_dev, int64_t ld, void *stream) {
+    API_BEGIN
+    HM_CHECK(out_dev != nullptr, "to_dense_device: null output");
+    device_to_dense_device(h->H, out_dev, (long long)ld, stream);
     API_END
 }
 int htool_hmatrix_factor_solve(const htool_hmatrix *h, int kind, char trans, void *B, int mu) {
     API_BEGIN
+    if (h->dfactor) {
+        HM_CHECK(device_dense_factor_kind(h->dfactor) == kind, kind == 1 ? "lu_solve: call lu_factorization first" : "cholesky_solve: call cholesky_factorization first");
+        HM_CHECK(trans == 'N' || trans == 'T', "factor solve: trans must be 'N' or 'T'");
+        device_dense_solve_host(h->H, h->dfactor, trans, B, mu);
+        return 0;
+    }
     const DenseFactor *f = (const DenseFactor *)h->factor;
     HM_CHECK(f != nullptr && f->kind == kind, kind == 1 ? "lu_solve: call lu_factorization first" : "cholesky_solve: call cholesky_factorization first");
     HM_CHECK(trans == 'N' || trans == 'T', "factor solve: trans must be 'N' or 'T'");
@@ -642,7 +691,10 @@ int htool_cluster_tiles(const htool_cluster *root, int partition_number, int til
 }
 
 } // extern "C"
-htool_hmatrix::~htool_hmatrix() { delete (DenseFactor *)factor; }
+htool_hmatrix::~htool_hmatrix() {
+    delete (DenseFactor *)factor;
+    device_dense_factor_free(dfactor);
+}
 extern "C" {
 int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.blocks.size(); }
 void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5) {

@@ -11,12 +11,21 @@ struct htool_cluster {}; // never instantiated: handles are hm::ClusterHandle
 struct htool_generator {
     hm::Generator g;
 };
+struct DeviceDenseFactor; // dense LU / Cholesky of an operator, held on the device (dense_device.hip)
 struct htool_hmatrix {
     hm::HMatrix H;
     hm::ClusterHandle *tch = nullptr, *sch = nullptr;
     void *factor = nullptr; // DenseFactor of the host fallback for lu/cholesky (capi.cpp)
+    DeviceDenseFactor *dfactor = nullptr; // ... or the device one (larger operators, partition-built blocks)
     ~htool_hmatrix();
 };
+// dense_device.hip
+void device_to_dense_device(const hm::HMatrix &H, void *out_dev, long long ld, void *stream);
+DeviceDenseFactor *device_dense_factor(const hm::HMatrix &H, int kind, char uplo, double shift);
+void device_dense_solve(const DeviceDenseFactor *f, char trans, void *B_dev, long long ldb, int mu, void *stream);
+void device_dense_solve_host(const hm::HMatrix &H, const DeviceDenseFactor *f, char trans, void *B, int mu);
+void device_dense_factor_free(DeviceDenseFactor *f);
+int device_dense_factor_kind(const DeviceDenseFactor *f);
 struct DistDeviceState; // device-side exchange buffers of a distributed operator (dist_device.hip)
 struct htool_distributed {
     htool_hmatrix *hmat = nullptr;

@@ -623,7 +623,16 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
         if (!p) return;
         size_t sz = 0;
         HIP_OK(hipMemPtrGetInfo(const_cast<void *>(p), &sz));
-        HIP_OK(dev_malloc(slot, std::max<size_t>(sz, 1)));
+        {
+            const hipError_t e = dev_malloc(slot, std::max<size_t>(sz, 1));
+            if (e != hipSuccess) { // (a copy needs the operator's memory a second time: say so instead of a bare HIP error)
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                (void)hipGetLastError();
+                throw Error(strprintf("out of device memory while copying an H-matrix: %.2f GB requested for one of its buffers, %.2f GB free of %.2f GB (%s) -- a deep copy "
+                                      "needs the operator's memory a second time", sz / 1e9, free_b / 1e9, total_b / 1e9, hipGetErrorString(e)));
+            }
+        }
         if (sz) HIP_OK(hipMemcpy(*slot, p, sz, hipMemcpyDeviceToDevice));
         map.push_back({(const char *)p, (const char *)p + sz, (char *)*slot});
     };

@@ -532,7 +532,17 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("get_distributed_information", [](const H &s, py::object) { return parse_info(s.h, 1); })
         .def("get_target_cluster", [](const H &s) { return PyCluster{s.target.owner, htool_hmatrix_target_cluster(s.h)}; })
         .def("get_source_cluster", [](const H &s) { return PyCluster{s.source.owner, htool_hmatrix_source_cluster(s.h)}; })
-        .def("lu_factorization", [](H &s) { check(htool_hmatrix_lu_factorization(s.h)); })
+        .def("lu_factorization", [](H &s) { py::gil_scoped_release nogil; check(htool_hmatrix_lu_factorization(s.h)); })
+        // extensions of the device path of the dense fallback (include/htool_mi355x.h): LU of (H + shift I), solves on device
+        // right-hand sides in the operator's cluster numbering, the dense expansion on the device
+        .def("lu_factorization_shifted", [](H &s, double shift) { py::gil_scoped_release nogil; check(htool_hmatrix_lu_factorization_shifted(s.h, shift)); }, "shift"_a)
+        .def("factor_solve_device", [](const H &s, int kind, char trans, std::uintptr_t b_dev, long long ldb, int mu, std::uintptr_t stream) {
+                check(htool_hmatrix_factor_solve_device(s.h, kind, trans, (void *)b_dev, ldb, mu, (void *)stream));
+            }, "kind"_a, "trans"_a, "b_ptr"_a, "ldb"_a, "mu"_a, "stream"_a = 0)
+        .def("to_dense_device", [](const H &s, std::uintptr_t out_dev, long long ld, std::uintptr_t stream) {
+                py::gil_scoped_release nogil;
+                check(htool_hmatrix_to_dense_device(s.h, (void *)out_dev, ld, (void *)stream));
+            }, "out_ptr"_a, "ld"_a, "stream"_a = 0)
         .def("cholesky_factorization", [](H &s, char UPLO) { check(htool_hmatrix_cholesky_factorization(s.h, UPLO)); })
         .def("lu_solve", [](const H &s, char trans, const py::array_t<T, py::array::f_style> &input) {
                 if (input.ndim() != 1 && input.ndim() != 2) throw std::runtime_error("Wrong dimension for HMatrix-LU input");

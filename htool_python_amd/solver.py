@@ -7,11 +7,12 @@ example/use_ddm_solver.py:49-69).  The reference delegates to HPDDM (absent); he
 package's own restarted GMRES on GPU-resident vectors (krylov.py) with the H-matrix product as operator.
 Only the options the reference's tests use are parsed (tests/test_ddm_solver.py:550-558):
 -hpddm_krylov_method gmres, -hpddm_tol, -hpddm_max_it, -hpddm_gmres_restart, -hpddm_variant right.
-`facto_one_level()` sets up a block-Jacobi preconditioner from the DENSE DIAGONAL LEAVES of this rank's H-matrix
-("Block-Jacobi via dense LU of small diagonal blocks"): the leaves (t, t) of the cluster-tree leaves tile
-the diagonal; they are downloaded once, LU-factorised as one padded batch (library call) and applied as a right
-preconditioner.  The reference's one-level Schwarz with an H-LU of the whole local block, and GenEO, are out of scope
-(SURVEY.md 2.1 row 12); the `block_diagonal_hmatrix` argument is accepted and ignored.
+`facto_one_level()` sets up the one-level right preconditioner.  As in the reference it is the inverse of the rank's whole
+diagonal block `block_diagonal_hmatrix` (one-level Schwarz without overlap) -- applied through a DENSE device factorisation of
+that block (DenseBlockLU; the reference uses a hierarchical LU, which this engine does not have) while the dense copy fits the
+device; otherwise (or without that block) block-Jacobi from the DENSE DIAGONAL LEAVES of this rank's H-matrix:
+the leaves (t, t) of the cluster-tree leaves tile the diagonal; they are downloaded once, LU-factorised as one padded batch
+(library call).  GenEO coarse spaces are out of scope.
 """
 import time
 
@@ -153,14 +154,56 @@ class BlockJacobi:
         return sol.reshape(-1)[self.index]
 
 
+class DenseBlockLU:
+    """M^-1 = (the rank's whole diagonal block + shift I)^-1: what the reference's `facto_one_level()` applies (one-level Schwarz
+    without overlap: the H-LU of `block_diagonal_hmatrix`, example/use_ddm_solver.py:48-63).  Here the block is expanded to a dense
+    matrix ON THE DEVICE and factorised by the dense solver library (htool_hmatrix_lu_factorization_shifted, dense_device.hip) --
+    a dense fallback, not a hierarchical factorisation: it is used while the dense copy fits comfortably (62 500 unknowns, the
+    per-GPU block of the 500 000-point configuration on 8 GPUs, are 31 GB)."""
+
+    def __init__(self, block_hmatrix, shift=0.0):
+        n, m = block_hmatrix.shape
+        if n != m:
+            raise RuntimeError("DenseBlockLU: the diagonal block is not square")
+        self.H, self.n = block_hmatrix, n
+        if shift != 0.0:
+            block_hmatrix.lu_factorization_shifted(float(shift))
+        else:
+            import os
+
+            old = os.environ.get("HTOOL_DENSE_FACTOR")
+            os.environ["HTOOL_DENSE_FACTOR"] = "device"  # (also for blocks below the host fallback's 20 000: the solve must be on the device)
+            try:
+                block_hmatrix.lu_factorization()
+            finally:
+                if old is None:
+                    os.environ.pop("HTOOL_DENSE_FACTOR", None)
+                else:
+                    os.environ["HTOOL_DENSE_FACTOR"] = old
+
+    @staticmethod
+    def fits(n, is_complex, fraction=0.35):
+        free, _total = torch.cuda.mem_get_info()
+        return n * n * (16 if is_complex else 8) * 1.1 <= fraction * free
+
+    def __call__(self, v):
+        """v: (size,) or (mu, size), this rank's slice in cluster numbering."""
+        out = v.clone() if v.dim() == 1 or v.stride(1) == 1 else v.contiguous().clone()
+        mu = 1 if out.dim() == 1 else out.shape[0]
+        ldb = self.n if out.dim() == 1 else out.stride(0)
+        self.H.factor_solve_device(1, "N", out.data_ptr(), max(ldb, 1), mu, torch.cuda.current_stream().cuda_stream)
+        return out
+
+
 class Solver:
-    def __init__(self, distributed_operator=None, hmatrix=None, shift=0.0):
+    def __init__(self, distributed_operator=None, hmatrix=None, shift=0.0, block_diagonal_hmatrix=None):
         from .krylov import gmres
 
         self._gmres = gmres
         self._opts = {"tol": 1e-6, "max_it": 200, "restart": 50}
         self._info = {}
         self._precond = None
+        self._block = block_diagonal_hmatrix
         if distributed_operator is not None:
             # the Krylov operator is the default H-matrix part only: an operator with extra user terms (add_global_to_local_operator /
             # add_local_to_local_operator, tests/conftest.py "ExtraDiagonal") or without an H-matrix core would be solved wrongly
@@ -179,10 +222,28 @@ class Solver:
             self.op = DeviceOperator(hmatrix, None, 0, None, shift)
         assert self.op.H.shape[1] == sum(s for _, s in self.op.partition), "GMRES needs a square operator"
         self._perm = np.asarray(self.op.H.get_source_cluster().get_permutation())
+        if len(self._perm) != self.op.H.shape[1]:  # a partition-built block: vectors are its slice in cluster order already
+            self._perm = np.arange(self.op.H.shape[1])
 
     def facto_one_level(self):
-        """Block-Jacobi on the dense diagonal leaves of the local rows (see module docstring)."""
+        """One-level preconditioner (src/htool/solver/solver.hpp: facto_one_level).  With the rank's `block_diagonal_hmatrix` at hand
+        and its dense copy fitting the device: the inverse of that whole block, as the reference (DenseBlockLU: a dense device
+        factorisation standing in for the H-LU).  Otherwise block-Jacobi on the dense diagonal leaves of the local rows."""
+        import logging
+
+        blk = self._block
+        if blk is not None and blk.shape == (self.op.size, self.op.size) and DenseBlockLU.fits(self.op.size, torch.zeros(0, dtype=self._dtype()).is_complex()):
+            self._precond = DenseBlockLU(blk, self.op.shift)
+            self._precond_name = "one-level: dense device LU of block_diagonal_hmatrix"
+            return
+        if blk is not None:
+            logging.getLogger("Htool").warning("facto_one_level: the dense copy of block_diagonal_hmatrix (%d unknowns) does not fit the device comfortably -- block-Jacobi on the "
+                                               "dense diagonal leaves instead (hierarchical LU is not part of this engine)", self.op.size)
         self._precond = BlockJacobi(self.op.H, self.op.offset, self.op.size, self.op.shift)
+        self._precond_name = "block-jacobi (dense diagonal leaves)"
+
+    def _dtype(self):
+        return torch.complex128 if type(self.op.H).__name__.startswith("Complex") else torch.float64
 
     def build_coarse_space(self, *a, **k):
         raise RuntimeError("GenEO coarse spaces are outside the MI355X hot path; not implemented")
@@ -225,7 +286,7 @@ class Solver:
         res = [h[-1] if h else 0.0 for h in hist]
         self._info = {"Nb_it": str(info["iterations"]), "Relative_residual": str(max(res)), "Solve_seconds": str(time.time() - t0),
                       "Products": str(self.op.products), "Krylov_method": "gmres",
-                      "Preconditioner": "none" if self._precond is None else "block-jacobi (dense diagonal leaves)"}
+                      "Preconditioner": "none" if self._precond is None else getattr(self, "_precond_name", "block-jacobi (dense diagonal leaves)")}
 
     def _gather(self, xl):
         """(mu, local size) device -> (mu, n) host, cluster numbering."""
@@ -245,23 +306,18 @@ class DDMSolverBuilder:
 
     Only the two-argument form of the reference (utility.hpp:14) is on the HIP path.  The reference factorises
     `block_diagonal_hmatrix` hierarchically in `facto_one_level()` (one-level Schwarz without overlap = block-Jacobi with the
-    rank's whole diagonal block); here `facto_one_level()` is block-Jacobi on the dense diagonal leaves of the rank's rows, so
-    the H-matrix handed in is kept (`get_local_hmatrix()`) but NOT factorised -- said once, at WARNING level.  The overlapping
-    forms (utility.hpp:16-40: subdomain numberings, neighbours, intersections) need HPDDM's Schwarz machinery and are refused."""
+    rank's whole diagonal block); here `facto_one_level()` factorises a DENSE copy of it on the device (DenseBlockLU) while that
+    fits, and falls back -- with a WARNING -- to block-Jacobi on the dense diagonal leaves of the rank's rows otherwise.  The
+    overlapping forms (utility.hpp:16-40: subdomain numberings, neighbours, intersections) need HPDDM's Schwarz machinery and
+    are refused."""
 
     def __init__(self, distributed_operator, block_diagonal_hmatrix=None, *args, **kwargs):
         if args or kwargs:
             raise RuntimeError("DDMSolverBuilder: only DDMSolverBuilder(distributed_operator, block_diagonal_hmatrix) is implemented on the HIP path; "
                                "the overlapping-subdomain constructors (src/htool/solver/utility.hpp:16-40) are outside it")
-        self.solver = Solver(distributed_operator)
+        self.solver = Solver(distributed_operator, block_diagonal_hmatrix=block_diagonal_hmatrix)
         self._local_hmatrix = block_diagonal_hmatrix
         self.local_to_global_numbering = None
-        if block_diagonal_hmatrix is not None:
-            import logging
-
-            logging.getLogger("Htool").warning(
-                "DDMSolverBuilder: block_diagonal_hmatrix is accepted but not factorised -- facto_one_level() sets up block-Jacobi on the dense "
-                "diagonal leaves of this rank's rows instead of the reference's hierarchical LU of the whole diagonal block")
 
     def get_local_hmatrix(self):
         return self._local_hmatrix

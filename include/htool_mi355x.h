@@ -192,13 +192,24 @@ int htool_hmatrix_matmat_device_trans(const htool_hmatrix *h, char trans, const 
 /* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
 int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);
 
-/* H-LU / H-Cholesky (hmatrix.hpp:58-94) are OUTSIDE the accelerated path.  So that code written for the
- * reference still runs, these entries densify the operator with GPU products and factorise it on the host
- * (partial pivoting, O(N^3), at most 20000 unknowns; a WARNING is logged).  kind: 1 = LU, 2 = Cholesky;
- * B is n x mu column-major in user numbering, overwritten by the solution. */
+/* H-LU / H-Cholesky (hmatrix.hpp:58-94): hierarchical factorisations are NOT part of this engine.  So that code written for the
+ * reference still runs -- in particular the one-level DDM preconditioner, which factorises the rank's diagonal block
+ * (example/use_ddm_solver.py:48-63) -- these entries factorise a DENSE copy of the operator:
+ *   - whole-cluster operators of at most 20000 unknowns: dense(H) by GPU products, factorised on the host (partial pivoting);
+ *   - larger operators and partition-built blocks (block_diagonal_hmatrix): dense(H) expanded ON THE DEVICE (sweeps of 16
+ *     unit vectors on the matrix cores) and factorised there by the dense solver library (rocSOLVER, loaded at run time);
+ *     the limit is the memory of the dense copy (62500 unknowns = 31 GB).  HTOOL_DENSE_FACTOR=device / host forces one path.
+ * A WARNING is logged either way.  kind: 1 = LU, 2 = Cholesky; B is n x mu column-major in user numbering (cluster order of
+ * the block for partition-built operators), overwritten by the solution. */
 int htool_hmatrix_lu_factorization(htool_hmatrix *h);
 int htool_hmatrix_cholesky_factorization(htool_hmatrix *h, char uplo);
 int htool_hmatrix_factor_solve(const htool_hmatrix *h, int kind, char trans, void *B, int mu);
+/* extensions of the device path: LU of (H + shift I); solves on DEVICE right-hand sides in the operator's cluster numbering
+ * (column c at B_dev + c * ldb), enqueued on stream -- what a Krylov loop applies as a preconditioner; the dense expansion by
+ * itself (column-major, leading dimension ld >= rows, cluster numbering of the rows and columns the operator covers) */
+int htool_hmatrix_lu_factorization_shifted(htool_hmatrix *h, double shift);
+int htool_hmatrix_factor_solve_device(const htool_hmatrix *h, int kind, char trans, void *B_dev, int64_t ldb, int mu, void *stream);
+int htool_hmatrix_to_dense_device(const htool_hmatrix *h, void *out_dev, int64_t ld, void *stream);
 
 /* host-only introspection (needs no GPU): the two work queues of the block cluster tree BEFORE the
  * leaves are filled -- admissible (to be compressed) and inadmissible (dense) -- as 4 ints per entry

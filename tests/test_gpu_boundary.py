@@ -235,3 +235,114 @@ def test_graph_replay_then_other_buffers(built, oracle):
         for i in range(3):
             assert torch.equal(ys[i], refs[i]) and torch.equal(Y[i], refs[i])
             ys[i].zero_()
+
+
+@pytest.mark.parametrize("case", ["real", "complex", "spd_cholesky", "one_triangle"])
+def test_dense_factorisation_on_the_device(built, oracle, monkeypatch, case):
+    """lu_factorization / lu_solve / cholesky_* (src/htool/hmatrix/hmatrix.hpp:58-94) through the DEVICE path of the dense fallback
+    (dense_device.hip: dense(H) expanded on the device by sweeps of 16 unit vectors, factorised by the dense solver library):
+    forced here for a small operator (HTOOL_DENSE_FACTOR=device; operators beyond 20 000 unknowns and partition-built blocks take
+    it by themselves).  Checks: the device expansion equals to_dense() (cluster numbering); A x = b and A^T x = b solved to the
+    accuracy of the operator; several right-hand sides; errors for a missing factorisation."""
+    import torch
+
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    monkeypatch.setenv("HTOOL_DENSE_FACTOR", "device")
+    n = 3000
+    np.random.seed(3)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 32)
+    cplx = case == "complex"
+    sym = ("S", "L") if case in ("spd_cholesky", "one_triangle") else ("N", "N")
+    if cplx:
+        H = Htool.ComplexHMatrixTreeBuilder(1e-9, 10.0, "N", "N").build(Htool.ComplexNativeGenerator("helmholtz", pts, pts, 2.0), cl, cl)
+        A = O.kernel_block(2, pts, pts, 2.0) if hasattr(O, "kernel_block") else None
+        shift = 0.0
+    else:
+        H = Htool.HMatrixTreeBuilder(1e-9, 10.0, *sym).build(Htool.NativeGenerator("inv_delta", pts, pts, 0.1), cl, cl)
+        A = O.kernel_block(0, pts, pts, 0.1)
+    # dense expansion on the device, cluster numbering
+    dt = torch.complex128 if cplx else torch.float64
+    Dd = torch.empty(n, n, dtype=dt, device="cuda")     # column-major n x n = row-major transpose
+    H.to_dense_device(Dd.data_ptr(), n, 0)
+    torch.cuda.synchronize()
+    dense_cluster = Dd.cpu().numpy().T
+    assert np.array_equal(dense_cluster, np.asarray(H.to_dense()))
+    perm = np.asarray(cl.get_permutation())
+    assert np.linalg.norm(dense_cluster - A[np.ix_(perm, perm)]) / np.linalg.norm(A) < 1e-8
+    rng = np.random.RandomState(0)
+    X = rng.rand(n, 3) + (1j * rng.rand(n, 3) if cplx else 0)
+    with pytest.raises(RuntimeError, match="factorization first"):
+        H.lu_solve("N", np.asfortranarray(A @ X))
+    if case == "spd_cholesky":
+        H.cholesky_factorization("L")
+        Y = H.cholesky_solve("L", np.asfortranarray(A @ X))
+        assert np.linalg.norm(Y - X) / np.linalg.norm(X) < 1e-5
+        return
+    H.lu_factorization()
+    Y = H.lu_solve("N", np.asfortranarray(A @ X))
+    assert np.linalg.norm(Y - X) / np.linalg.norm(X) < 1e-5
+    Yt = H.lu_solve("T", np.asfortranarray(A.T @ X))
+    assert np.linalg.norm(Yt - X) / np.linalg.norm(X) < 1e-5
+    y1 = H.lu_solve("N", np.ascontiguousarray((A @ X)[:, 0]))
+    assert y1.shape == (n,) and np.linalg.norm(y1 - X[:, 0]) / np.linalg.norm(X[:, 0]) < 1e-5
+    # device right-hand sides in cluster numbering (what the Krylov loop hands over)
+    B = torch.from_numpy(np.ascontiguousarray((A @ X)[perm].T)).cuda()   # (mu, n): row c = right-hand side c
+    H.factor_solve_device(1, "N", B.data_ptr(), n, 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.linalg.norm(B.cpu().numpy().T - X[perm]) / np.linalg.norm(X) < 1e-5
+    # the shifted factorisation of the solver's bench system
+    H.lu_factorization_shifted(0.5)
+    Ys = H.lu_solve("N", np.asfortranarray((A + 0.5 * np.eye(n)) @ X))
+    assert np.linalg.norm(Ys - X) / np.linalg.norm(X) < 1e-6
+
+
+def test_one_level_preconditioner_at_the_per_gpu_block_of_c5(built, oracle):
+    """VERDICT round 2, item 8 (done criterion): lu_solve at 62 500 unknowns -- the per-rank diagonal block of BASELINE config C5
+    (500 000 points on 8 GPUs) -- and facto_one_level() using it.  The block (partition 3 x partition 3 of the 8-way split) is built
+    as DefaultApproximationBuilder.block_diagonal_hmatrix builds it, factorised through the dense device fallback (31 GB dense
+    copy; a hierarchical LU is not part of this engine), and used (a) by lu_solve on host vectors, (b) as the one-level
+    preconditioner of GMRES on the block's own system, which then converges at once."""
+    import Htool
+    from htool_python_amd.solver import Solver
+    from htool_python_amd.workloads import points_in_sphere
+
+    O = oracle
+    n, world, p = 500_000, 8, 3
+    pts = points_in_sphere(n, seed=0)
+    b = Htool.ClusterTreeBuilder()
+    b.set_maximal_leaf_size(100)
+    cl = b.create_cluster_tree(pts, 2, size_of_partition=world)
+    sub = cl.get_cluster_on_partition(p)
+    off, size = sub.get_offset(), sub.get_size()
+    assert size == n // world
+    gen = Htool.NativeGenerator("inv_delta", pts, pts, 0.1)
+    Hb = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N").build_local(gen, cl, cl, p, p)
+    assert Hb.shape == (size, size)
+    perm = np.asarray(cl.get_permutation())
+    local_pts = np.asfortranarray(pts[:, perm[off:off + size]])
+    rng = np.random.RandomState(1)
+    x_ref = rng.rand(size)
+    bb = Hb * x_ref                                   # the block's own product (cluster order of the slice on both sides)
+    rows = rng.choice(size, 64, replace=False)
+    be = O.dense_matvec(0, local_pts, local_pts, x_ref, 0.1, rows=rows)
+    assert np.linalg.norm(bb[rows] - be) / np.linalg.norm(be) < 1e-6
+    Hb.lu_factorization()                             # partition-built block: the device path by itself
+    x = Hb.lu_solve("N", bb)
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    # the exact operator's right-hand side on sampled rows is reproduced by the solution too (epsilon of the operator)
+    assert np.linalg.norm(O.dense_matvec(0, local_pts, local_pts, x, 0.1, rows=rows) - be) / np.linalg.norm(be) < 1e-5
+    # facto_one_level(): GMRES on the block's system, preconditioned by its own factorisation
+    solver = Solver(hmatrix=Hb, block_diagonal_hmatrix=Hb)
+    solver.set_hpddm_args("-hpddm_tol 1e-10 -hpddm_max_it 50 -hpddm_gmres_restart 20")
+    solver.facto_one_level()
+    xs = np.zeros(size)
+    solver.solve(xs, bb)
+    info = solver.get_information()
+    assert "dense device LU" in info["Preconditioner"] and int(info["Nb_it"]) <= 3, info
+    assert np.linalg.norm(xs - x_ref) / np.linalg.norm(x_ref) < 1e-6
+    del solver, Hb
+    Htool.release_workspace()

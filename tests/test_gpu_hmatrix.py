@@ -525,6 +525,17 @@ def test_block_jacobi_preconditioned_gmres(built, oracle, symmetry, uplo):
     xs = np.zeros(n)
     solver.solve(xs, b)
     info = solver.get_information()
+    # round 3: with block_diagonal_hmatrix at hand (one rank: the operator itself) facto_one_level() inverts that whole block -- a dense
+    # device factorisation standing in for the reference's H-LU -- so the preconditioned system is solved at once
+    assert "dense device LU" in info["Preconditioner"] and int(info["Nb_it"]) <= 3
+    assert np.linalg.norm(A @ xs - b) / np.linalg.norm(b) < 1e-6
+    # without the block: block-Jacobi on the dense diagonal leaves, the iteration count of the raw loop above
+    solver = Htool.DDMSolverBuilder(approx.distributed_operator).solver
+    solver.set_hpddm_args("-hpddm_tol 1e-9 -hpddm_max_it 600 -hpddm_gmres_restart 60")
+    solver.facto_one_level()
+    xs = np.zeros(n)
+    solver.solve(xs, b)
+    info = solver.get_information()
     assert "block-jacobi" in info["Preconditioner"] and int(info["Nb_it"]) == prec["iterations"]
     assert np.linalg.norm(A @ xs - b) / np.linalg.norm(b) < 1e-6
 

@@ -12,7 +12,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Wall -Wno-unused-result $flags -c $P/csrc/device.hip -o $P/_variants/device.$name.o
   g++ -shared -o $P/_variants/libhtool_mi355x.$name.so $P/_obj/util.cpp.o $P/_obj/cluster.cpp.o $P/_obj/blocktree.cpp.o $P/_obj/layout.cpp.o $P/_obj/build_host.cpp.o $P/_obj/capi.cpp.o \
-      $P/_variants/device.$name.o $P/_obj/dist_device.hip.o $P/_obj/krylov_device.hip.o -fopenmp -L/opt/rocm/lib -lamdhip64 -lrccl -Wl,-rpath,/opt/rocm/lib
+      $P/_variants/device.$name.o $P/_obj/dist_device.hip.o $P/_obj/krylov_device.hip.o $P/_obj/dense_device.hip.o -fopenmp -L/opt/rocm/lib -lamdhip64 -lrccl -ldl -Wl,-rpath,/opt/rocm/lib
   rm -f $P/_variants/device.$name.o
   mkdir -p $P/_variants/$name
   cp $P/_variants/libhtool_mi355x.$name.so $P/_variants/$name/libhtool_mi355x.so

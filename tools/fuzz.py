@@ -51,6 +51,10 @@ def main(budget, seed, only_case=None, with_oracle=False):
         children = int(rng.choice([2, 2, 2, 3, 4]))
         strategy = str(rng.choice(["PCARegular", "PCAGeometric", "BoundingBoxRegular", "BoundingBoxGeometric"]))
         arena = None if rng.rand() < 0.6 else int(10 ** rng.uniform(1.3, 2.7))
+        if arena is not None and not os.environ.get("FUZZ_TINY_ARENAS"):
+            # the forced arena is there to exercise multi-round builds, not thousands of rounds: seed 42 case 43 (0.49 M x 0.54 M points,
+            # complex, eps 1e-7, 76 MB) needed 3848 rounds and 143 s for the build alone (gpurun_out/r03e/fuzz_42_43.log)
+            arena = max(arena, int(max(n, ns) / 400))
         recompress = rng.rand() < 0.3 and eps <= 1e-4
         shape = str(rng.choice(["ball", "cube", "sheet", "clustered"]))
         part = int(rng.choice([2, 3, 4, 8])) if (square and sym == "N" and rng.rand() < 0.35) else 1   # rows of one partition (a rank's share)
@@ -99,6 +103,8 @@ def main(budget, seed, only_case=None, with_oracle=False):
             Gen = Htool.ComplexNativeGenerator if cplx else Htool.NativeGenerator
             b = Builder(eps, eta, sym, uplo)
             b.set_symmetric_storage(one_tri)
+            confirm = int(os.environ.get("FUZZ_CONFIRM", "0"))  # confirmation steps of the ACA stopping test (0 = the reference's rule)
+            b.set_aca_confirmation_steps(confirm)
             t0 = time.time()
             if part > 1:   # the per-rank operator of a row split: local rows in cluster order, x in user numbering
                 H = b.build(Gen(kind, pt, ps, p0), ct, cs, which)
@@ -156,7 +162,7 @@ def main(budget, seed, only_case=None, with_oracle=False):
                 sid = {"PCARegular": 0, "PCAGeometric": 1, "BoundingBoxRegular": 2, "BoundingBoxGeometric": 3}[strategy]
                 oc = O.Cluster(pt, n_children=children, size_of_partition=1, max_leaf=leaf, strategy=sid)
                 ocs = oc if square else O.Cluster(ps, n_children=children, size_of_partition=1, max_leaf=leaf, strategy=sid)
-                OH = O.HMatrix(oc, ocs, {"inv_delta": 0, "laplace": 1, "helmholtz": 2}[kind], p0, is_complex=cplx, eps=eps, eta=eta, symmetry=sym, uplo=uplo)
+                OH = O.HMatrix(oc, ocs, {"inv_delta": 0, "laplace": 1, "helmholtz": 2}[kind], p0, is_complex=cplx, eps=eps, eta=eta, symmetry=sym, uplo=uplo, confirm=confirm)
                 yo = OH.matvec(x)
                 print(f"   oracle: err {np.linalg.norm(yo[rows] - ye) / scale:.2e}, |y - y_oracle|/|y| {np.linalg.norm(y - yo) / np.linalg.norm(yo):.2e}", flush=True)
             print(("ok  " if ok else "FAIL"), f"{time.time() - t0:6.2f}s err {err:.2e} errT {errT:.2e}", label, flush=True)
