@@ -33,12 +33,13 @@ struct SolverLib {
     rb_status (*create_handle)(rb_handle *) = nullptr;
     rb_status (*destroy_handle)(rb_handle) = nullptr;
     rb_status (*set_stream)(rb_handle, hipStream_t) = nullptr;
-    rb_status (*dgetrf)(rb_handle, int, int, double *, int, int *, int *) = nullptr;
-    rb_status (*zgetrf)(rb_handle, int, int, rb_z *, int, int *, int *) = nullptr;
-    rb_status (*dgetrs)(rb_handle, int, int, int, double *, int, const int *, double *, int) = nullptr;
-    rb_status (*zgetrs)(rb_handle, int, int, int, rb_z *, int, const int *, rb_z *, int) = nullptr;
-    rb_status (*dpotrf)(rb_handle, int, int, double *, int, int *) = nullptr;
-    rb_status (*dpotrs)(rb_handle, int, int, int, double *, int, double *, int) = nullptr;
+    // the 64-bit interface: a 62 500 x 62 500 matrix has more entries than a 32-bit integer counts
+    rb_status (*dgetrf)(rb_handle, int64_t, int64_t, double *, int64_t, int64_t *, int64_t *) = nullptr;
+    rb_status (*zgetrf)(rb_handle, int64_t, int64_t, rb_z *, int64_t, int64_t *, int64_t *) = nullptr;
+    rb_status (*dgetrs)(rb_handle, int, int64_t, int64_t, double *, int64_t, const int64_t *, double *, int64_t) = nullptr;
+    rb_status (*zgetrs)(rb_handle, int, int64_t, int64_t, rb_z *, int64_t, const int64_t *, rb_z *, int64_t) = nullptr;
+    rb_status (*dpotrf)(rb_handle, int, int64_t, double *, int64_t, int64_t *) = nullptr;
+    rb_status (*dpotrs)(rb_handle, int, int64_t, int64_t, double *, int64_t, double *, int64_t) = nullptr;
     std::string error;
     bool load() {
         if (solver) return true;
@@ -51,12 +52,12 @@ struct SolverLib {
         *(void **)&create_handle = sym(blas, "rocblas_create_handle");
         *(void **)&destroy_handle = sym(blas, "rocblas_destroy_handle");
         *(void **)&set_stream = sym(blas, "rocblas_set_stream");
-        *(void **)&dgetrf = sym(s, "rocsolver_dgetrf");
-        *(void **)&zgetrf = sym(s, "rocsolver_zgetrf");
-        *(void **)&dgetrs = sym(s, "rocsolver_dgetrs");
-        *(void **)&zgetrs = sym(s, "rocsolver_zgetrs");
-        *(void **)&dpotrf = sym(s, "rocsolver_dpotrf");
-        *(void **)&dpotrs = sym(s, "rocsolver_dpotrs");
+        *(void **)&dgetrf = sym(s, "rocsolver_dgetrf_64");
+        *(void **)&zgetrf = sym(s, "rocsolver_zgetrf_64");
+        *(void **)&dgetrs = sym(s, "rocsolver_dgetrs_64");
+        *(void **)&zgetrs = sym(s, "rocsolver_zgetrs_64");
+        *(void **)&dpotrf = sym(s, "rocsolver_dpotrf_64");
+        *(void **)&dpotrs = sym(s, "rocsolver_dpotrs_64");
         if (!error.empty()) return false;
         solver = s;
         return true;
@@ -127,12 +128,12 @@ struct DeviceDenseFactor {
     bool is_complex = false;
     char uplo = 'L';
     void *a = nullptr;
-    int *ipiv = nullptr, *info = nullptr;
+    int64_t *ipiv = nullptr, *info = nullptr;
     rb_handle handle = nullptr;
     ~DeviceDenseFactor() {
         (void)hipSetDevice(device);
         if (handle && g_solver.destroy_handle) (void)g_solver.destroy_handle(handle);
-        for (void *p : {a, (void *)ipiv, (void *)info}) if (p) (void)hipFree(p);
+            for (void *p : {a, (void *)ipiv, (void *)info}) if (p) (void)hipFree(p);
     }
 };
 void device_dense_factor_free(DeviceDenseFactor *f) { delete f; }
@@ -158,11 +159,12 @@ DeviceDenseFactor *device_dense_factor(const HMatrix &H, int kind, char uplo, do
     HM_CHECK(need <= (double)free_b, strprintf("factorization: the dense copy of the %d x %d operator needs %.1f GB, %.1f GB are free -- hierarchical LU is not part of this engine", n, n,
                                                need / 1e9, free_b / 1e9));
     HIP_OK(hipMalloc(&f->a, std::max<size_t>((size_t)n * n * es, 1)));
-    HIP_OK(hipMalloc((void **)&f->ipiv, sizeof(int) * std::max(n, 1)));
-    HIP_OK(hipMalloc((void **)&f->info, sizeof(int)));
+    HIP_OK(hipMalloc((void **)&f->ipiv, sizeof(int64_t) * std::max(n, 1)));
+    HIP_OK(hipMalloc((void **)&f->info, sizeof(int64_t)));
     const double t0 = wall_seconds();
     device_to_dense_device(H, f->a, n, D->stream);
     const double t1 = wall_seconds();
+    log_message(LOG_DEBUG, strprintf("dense copy of the %d x %d operator on the device: %.3f s", n, n, t1 - t0));
     if (shift != 0.0 && n > 0) {
         if (H.is_complex) hipLaunchKernelGGL(add_to_diagonal_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, D->stream, (double2 *)f->a, (long long)n, n, shift);
         else hipLaunchKernelGGL(add_to_diagonal_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, D->stream, (double *)f->a, (long long)n, n, shift);
@@ -173,8 +175,8 @@ DeviceDenseFactor *device_dense_factor(const HMatrix &H, int kind, char uplo, do
     if (kind == 1) rs = H.is_complex ? g_solver.zgetrf(f->handle, n, n, (rb_z *)f->a, n, f->ipiv, f->info) : g_solver.dgetrf(f->handle, n, n, (double *)f->a, n, f->ipiv, f->info);
     else rs = g_solver.dpotrf(f->handle, uplo == 'U' ? RB_UPPER : RB_LOWER, n, (double *)f->a, n, f->info);
     HM_CHECK(rs == 0, strprintf("the dense solver library reported status %d", rs));
-    int info = 0;
-    HIP_OK(hipMemcpyAsync(&info, f->info, sizeof(int), hipMemcpyDeviceToHost, D->stream));
+    int64_t info = 0;
+    HIP_OK(hipMemcpyAsync(&info, f->info, sizeof(int64_t), hipMemcpyDeviceToHost, D->stream));
     HIP_OK(hipStreamSynchronize(D->stream));
     HM_CHECK(info == 0, kind == 1 ? "lu_factorization: singular matrix" : "cholesky_factorization: matrix is not positive definite");
     log_message(LOG_INFO, strprintf("dense %s of the %d x %d operator on the device: expansion %.3f s, factorisation %.3f s (dense fallback: hierarchical LU is not part of this engine)",
@@ -193,9 +195,9 @@ void device_dense_solve(const DeviceDenseFactor *f, char trans, void *B_dev, lon
     rb_status rs;
     if (f->kind == 1) {
         const int op = trans == 'N' ? RB_OP_N : (trans == 'C' && f->is_complex ? RB_OP_C : RB_OP_T);
-        rs = f->is_complex ? g_solver.zgetrs(f->handle, op, f->n, mu, (rb_z *)f->a, f->n, f->ipiv, (rb_z *)B_dev, (int)ldb)
-                           : g_solver.dgetrs(f->handle, op, f->n, mu, (double *)f->a, f->n, f->ipiv, (double *)B_dev, (int)ldb);
-    } else rs = g_solver.dpotrs(f->handle, f->uplo == 'U' ? RB_UPPER : RB_LOWER, f->n, mu, (double *)f->a, f->n, (double *)B_dev, (int)ldb);
+        rs = f->is_complex ? g_solver.zgetrs(f->handle, op, f->n, mu, (rb_z *)f->a, f->n, f->ipiv, (rb_z *)B_dev, (int64_t)ldb)
+                           : g_solver.dgetrs(f->handle, op, f->n, mu, (double *)f->a, f->n, f->ipiv, (double *)B_dev, (int64_t)ldb);
+    } else rs = g_solver.dpotrs(f->handle, f->uplo == 'U' ? RB_UPPER : RB_LOWER, f->n, mu, (double *)f->a, f->n, (double *)B_dev, (int64_t)ldb);
     HM_CHECK(rs == 0, strprintf("the dense solver library reported status %d", rs));
 }
 

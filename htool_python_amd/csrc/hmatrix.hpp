@@ -79,7 +79,11 @@ struct BatchLayout {
     std::vector<Reduce> z_reduces;
     std::vector<int> zd_tile;        // row tile (of y) receiving a dense leaf's A^T x ...
     std::vector<int64_t> zd_woff;    // ... which starts at this index of W
-    // pack work items (block index into `blocks`, tile id)
+    // pack work items (block index into `blocks`, tile id): (leaf, row tile) and (low-rank leaf, source tile) pairs in leaf order.
+    // u_first / v_first (n_blocks + 1 entries) say where a leaf's items start; the item lists themselves are written here only when
+    // host_items is set -- the build expands them on the device from the two prefix arrays (75 MB less to upload at 1 M points)
+    bool host_items = true;
+    std::vector<int> u_first, v_first;
     std::vector<int> u_item_block, u_item_tile, v_item_block, v_item_tile;
 };
 

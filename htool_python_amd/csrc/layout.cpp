@@ -167,6 +167,7 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
     }
 
     // ---- pack work items: (leaf, row tile) and (low-rank leaf, source tile) pairs in leaf order; counted, then written by all threads
+    // (or expanded on the device from the counts: L.host_items = false)
     const size_t nb = batch_blocks.size();
     std::vector<int64_t> u_first(nb + 1, 0), v_first(nb + 1, 0);
     for (size_t q = 0; q < nb; q++) {
@@ -174,6 +175,10 @@ void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, 
         u_first[q + 1] = u_first[q] + (H.rtiles.node_tile_end[b.t_node] - H.rtiles.node_tile_begin[b.t_node]);
         v_first[q + 1] = v_first[q] + (b.rank >= 0 ? H.ctiles.node_tile_end[b.s_node] - H.ctiles.node_tile_begin[b.s_node] : 0);
     }
+    HM_CHECK(u_first[nb] < ((int64_t)1 << 31) && v_first[nb] < ((int64_t)1 << 31), "a batch has more pack work items than a 32-bit index counts");
+    L.u_first.assign(u_first.begin(), u_first.end());
+    L.v_first.assign(v_first.begin(), v_first.end());
+    if (!L.host_items) return;
     L.u_item_block.resize((size_t)u_first[nb]); L.u_item_tile.resize((size_t)u_first[nb]);
     L.v_item_block.resize((size_t)v_first[nb]); L.v_item_tile.resize((size_t)v_first[nb]);
     parallel_for((long long)nb, [&](long long q) {
