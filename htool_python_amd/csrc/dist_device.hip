@@ -89,6 +89,32 @@ int rccl_allgather_device(void *ctx, const void *send_dev, void *recv_dev, int64
     return 0;
 }
 
+// htool_comm.reduce_scatter_device of an RCCL communicator: sums of doubles, chunk `rank` of everybody's buffer, in stream order
+int rccl_reduce_scatter_device(void *ctx, const void *send_dev, void *recv_dev, int64_t count, void *stream) {
+    RcclComm *c = static_cast<RcclComm *>(ctx);
+    try {
+        HM_CHECK(c && c->comm, "RCCL communicator already destroyed");
+        RCCL_OK(ncclReduceScatter(send_dev, recv_dev, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
+    } catch (const std::exception &e) {
+        htool_error_slot() = e.what();
+        return 1;
+    }
+    return 0;
+}
+
+// the inverse of compact_slices_kernel: z_full[c][displs[p] : +counts[p])  ->  padded[p][c][0 : pad), zeros behind the slice
+template <typename T>
+__global__ void expand_slices_kernel(const T *__restrict__ z_full, T *__restrict__ padded, const int *__restrict__ counts, const int *__restrict__ displs, int pad, int mu,
+                                     long long ldz) {
+    const int p = blockIdx.y, c = blockIdx.z;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pad) return;
+    T v;
+    if (i < counts[p]) v = z_full[(long long)c * ldz + displs[p] + i];
+    else { double *q = reinterpret_cast<double *>(&v); for (size_t k = 0; k < sizeof(T) / 8; k++) q[k] = 0.0; }
+    padded[((long long)p * mu + c) * pad + i] = v;
+}
+
 // gathered[p][c][0 : pad)  ->  x_full[c][displs[p] : displs[p] + counts[p])   (one launch for all ranks and columns)
 template <typename T>
 __global__ void compact_slices_kernel(const T *__restrict__ gathered, T *__restrict__ x_full, const int *__restrict__ counts, const int *__restrict__ displs, int pad, int mu,
@@ -234,7 +260,91 @@ static void dist_matmat_device(htool_distributed *d, const void *X_local, int64_
     device_matmat_device(H, s->x_full, (long long)ns, Y_local, (long long)ldy, mu, 1, caller_stream); // (NULL: the operator's own stream, = st)
 }
 
+// sum over the ranks of everybody's chunk `rank`: send_dev holds P chunks of `count` doubles, recv_dev receives one (stream order)
+static void reduce_scatter_doubles(htool_distributed *d, DistDeviceState *s, const void *send_dev, void *recv_dev, size_t count, hipStream_t st) {
+    const int P = d->comm.size, rank = d->comm.rank;
+    if (d->comm.reduce_scatter_device) {
+        const int rc = d->comm.reduce_scatter_device(d->comm.ctx, send_dev, recv_dev, (int64_t)count, (void *)st);
+        HM_CHECK(rc == 0, std::string("distributed device product: reduce_scatter_device failed: ") + htool_error_slot());
+        return;
+    }
+    // host-staged (several ranks on one GPU): everybody's whole buffer is gathered on the host, the own chunk summed in rank order
+    HM_CHECK(d->comm.allgatherv != nullptr, "distributed device product: the communicator has neither reduce_scatter_device (htool_comm_init_rccl / htool_comm_wrap_rccl) nor allgatherv");
+    const size_t bytes = count * P * sizeof(double);
+    if (bytes > s->h_cap) {
+        if (s->h_send) (void)hipHostFree(s->h_send);
+        if (s->h_recv) (void)hipHostFree(s->h_recv);
+        s->h_send = s->h_recv = nullptr;
+        s->h_cap = 0;
+        HIP_OK(hipHostMalloc(&s->h_send, bytes, hipHostMallocDefault));
+        HIP_OK(hipHostMalloc(&s->h_recv, bytes * P, hipHostMallocDefault));
+        s->h_cap = bytes;
+    }
+    HIP_OK(hipMemcpyAsync(s->h_send, send_dev, bytes, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    std::vector<int64_t> cnt((size_t)P, (int64_t)bytes), dsp((size_t)P);
+    for (int p = 0; p < P; p++) dsp[p] = (int64_t)p * (int64_t)bytes;
+    const int rc = d->comm.allgatherv(d->comm.ctx, s->h_send, (int64_t)bytes, s->h_recv, cnt.data(), dsp.data());
+    HM_CHECK(rc == 0, "distributed device product: allgatherv failed");
+    double *acc = (double *)s->h_send; // (reused: the own chunk, summed over the ranks in rank order)
+    const double *all = (const double *)s->h_recv;
+    for (size_t i = 0; i < count; i++) {
+        double v = 0;
+        for (int p = 0; p < P; p++) v += all[(size_t)p * count * P + (size_t)rank * count + i];
+        acc[i] = v;
+    }
+    HIP_OK(hipMemcpyAsync(recv_dev, acc, count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st)); // (acc is overwritten by the next call's device -> host copy)
+}
+
+// Y_local = op(A) X restricted to this rank's source slice, X given by the rows this rank owns (see the header)
+static void dist_matmat_device_trans(htool_distributed *d, char trans, const void *X_local, int64_t ldx, void *Y_local, int64_t ldy, int mu, hipStream_t caller_stream) {
+    hipStream_t st = caller_stream;
+    const HMatrix &H = d->hmat->H;
+    const size_t es = H.is_complex ? 16 : 8;
+    const int P = d->comm.size, rank = d->comm.rank;
+    HM_CHECK(mu >= 1, "mu must be >= 1");
+    HM_CHECK(trans == 'T' || trans == 'C', "distributed transposed product: trans must be 'T' or 'C'");
+    HM_CHECK(H.dev != nullptr, "H-matrix has no device data");
+    if (!st) st = H.dev->stream;
+    if (d->comm.size == 1 && !d->comm.reduce_scatter_device && !force_padded()) { // one rank owns everything
+        device_matmat_device(H, X_local, (long long)ldx, Y_local, (long long)ldy, mu, 1, caller_stream, trans);
+        return;
+    }
+    DistDeviceState *s = dist_state(d, mu);
+    HIP_OK(hipSetDevice(s->device));
+    const int mine = (int)d->s_counts[rank];
+    const size_t ns = (size_t)d->sc->n_points;
+    const size_t dbl = es / sizeof(double);
+    // the local block applied transposed: a full-length vector (cluster numbering of the source tree), reusing the buffer of the gathered x
+    device_matmat_device(H, X_local, (long long)ldx, s->x_full, (long long)ns, mu, 1, caller_stream, trans);
+    if (s->equal && mu == 1) { // rank p's slice sits at p * pad: reduce-scatter straight from the vector into the caller's buffer
+        reduce_scatter_doubles(d, s, s->x_full, Y_local, (size_t)s->pad * dbl, st);
+        return;
+    }
+    const dim3 grid((unsigned)((s->pad + 255) / 256), (unsigned)P, (unsigned)mu), block(256);
+    if (s->pad > 0) {
+        if (H.is_complex) hipLaunchKernelGGL(expand_slices_kernel<double2>, grid, block, 0, st, (const double2 *)s->x_full, (double2 *)s->recv, s->counts, s->displs, s->pad, mu, (long long)ns);
+        else hipLaunchKernelGGL(expand_slices_kernel<double>, grid, block, 0, st, (const double *)s->x_full, (double *)s->recv, s->counts, s->displs, s->pad, mu, (long long)ns);
+        HIP_OK(hipGetLastError());
+    }
+    reduce_scatter_doubles(d, s, s->recv, s->send, (size_t)s->pad * mu * dbl, st); // [p][c][pad] summed -> [c][pad]
+    if (mine > 0) {
+        if (mu == 1) HIP_OK(hipMemcpyAsync(Y_local, s->send, (size_t)mine * es, hipMemcpyDeviceToDevice, st));
+        else {
+            HM_CHECK(ldy >= mine, "distributed transposed product: ldy is smaller than this rank's slice");
+            HIP_OK(hipMemcpy2DAsync(Y_local, (size_t)ldy * es, s->send, (size_t)s->pad * es, (size_t)mine * es, (size_t)mu, hipMemcpyDeviceToDevice, st));
+        }
+    }
+}
+
 extern "C" {
+
+int htool_distributed_matmat_device_trans(htool_distributed *d, char trans, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream) {
+    API_BEGIN
+    dist_matmat_device_trans(d, trans, X_local_dev, ldx, Y_local_dev, ldy, mu, (hipStream_t)stream);
+    API_END
+}
 
 int htool_rccl_get_unique_id(void *id128) {
     API_BEGIN
@@ -260,6 +370,7 @@ int htool_comm_init_rccl(const void *id128, int rank, int size, htool_comm *out)
     out->size = size;
     out->allgatherv = &rccl_host_allgatherv;
     out->allgather_device = &rccl_allgather_device;
+    out->reduce_scatter_device = &rccl_reduce_scatter_device;
     out->rccl = c.get();
     out->ctx = c.release();
     API_END
@@ -278,6 +389,7 @@ int htool_comm_wrap_rccl(void *nccl_comm, int rank, int size, htool_comm *out) {
     out->size = size;
     out->allgatherv = &rccl_host_allgatherv;
     out->allgather_device = &rccl_allgather_device;
+    out->reduce_scatter_device = &rccl_reduce_scatter_device;
     out->rccl = c.get();
     out->ctx = c.release();
     API_END
@@ -289,6 +401,7 @@ void htool_comm_destroy_rccl(htool_comm *c) {
         c->rccl = c->ctx = nullptr;
         c->allgatherv = nullptr;
         c->allgather_device = nullptr;
+        c->reduce_scatter_device = nullptr;
     }
 }
 

@@ -728,6 +728,9 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
         .def("matmat_device", [](Op &o, std::uintptr_t x_local, long long ldx, std::uintptr_t y_local, long long ldy, int mu, std::uintptr_t stream) {
                 check(htool_distributed_matmat_device(o.d, (const void *)x_local, ldx, (void *)y_local, ldy, mu, (void *)stream));
             }, "x_local_ptr"_a, "ldx"_a, "y_local_ptr"_a, "ldy"_a, "mu"_a, "stream"_a = 0)
+        .def("matmat_device_trans", [](Op &o, char trans, std::uintptr_t x_local, long long ldx, std::uintptr_t y_local, long long ldy, int mu, std::uintptr_t stream) {
+                check(htool_distributed_matmat_device_trans(o.d, trans, (const void *)x_local, ldx, (void *)y_local, ldy, mu, (void *)stream));
+            }, "trans"_a, "x_local_ptr"_a, "ldx"_a, "y_local_ptr"_a, "ldy"_a, "mu"_a, "stream"_a = 0)
         .def_property_readonly("has_rccl", [](Op &o) { return o.comm->c.rccl != nullptr; })
         // which exchange matvec_device / matmat_device run (htool_distributed_exchange_kind): 0 none, 1 zero-copy, 2 padded + compaction,
         // 3 / 4 the same staged through the host all-gather of the communicator object, -1 not possible

@@ -196,6 +196,14 @@ class DistributedOperator:
             raise RuntimeError("matmat_device: only the default H-matrix operator has a device-resident product")
         self._core.matmat_device(x_local_ptr, ldx, y_local_ptr, ldy, mu, stream)
 
+    def matmat_device_trans(self, trans, x_local_ptr, ldx, y_local_ptr, ldy, mu, stream=0):
+        """The transposed ('T') or conjugate-transposed ('C') product with the same distribution (an extension: the reference's
+        Python surface only passes 'N'): this rank's slice of x -- the rows it owns -- in, its slice of y (source partition
+        `rank`) out, device pointers in cluster numbering; one reduce-scatter inside the library (htool_distributed_matmat_device_trans)."""
+        if not self.has_only_default_operator():
+            raise RuntimeError("matmat_device_trans: only the default H-matrix operator has a device-resident product")
+        self._core.matmat_device_trans(trans, x_local_ptr, ldx, y_local_ptr, ldy, mu, stream)
+
     def has_only_default_operator(self):
         return self._core is not None and not self._g2l and not self._l2l
 

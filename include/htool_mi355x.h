@@ -284,6 +284,11 @@ typedef struct htool_comm {
      * compaction, local product -- with several ranks sharing ONE GPU (tests, rehearsals).  A host language may also install
      * its own (the ctypes tests do, to play rank r of P in a single process). */
     int (*allgather_device)(void *ctx, const void *send_dev, void *recv_dev, int64_t bytes, void *stream);
+    /* (d) the exchange step of the TRANSPOSED GPU-resident product (htool_distributed_matmat_device_trans): reduce-scatter of
+     * doubles on device buffers, enqueued on `stream` -- send_dev holds size * count doubles, recv_dev receives the SUM over
+     * the ranks of everybody's chunk number `rank` (count doubles).  htool_comm_init_rccl / _wrap_rccl install
+     * ncclReduceScatter.  NULL: staged through the host and allgatherv by the library, as for (c). */
+    int (*reduce_scatter_device)(void *ctx, const void *send_dev, void *recv_dev, int64_t count, void *stream);
 } htool_comm;
 /* RCCL bootstrap (the NCCL pattern): ONE rank obtains a unique id, the host language broadcasts its 128 bytes to the
  * other ranks by its own means, then every rank calls htool_comm_init_rccl on the device it selected with
@@ -316,6 +321,13 @@ int htool_distributed_matmat(const htool_distributed *d, const void *X, int mu, 
  * The matmat form takes mu columns (column c at X_local + c * ldx elements) in one exchange. */
 int htool_distributed_matvec_device(htool_distributed *d, const void *x_local_dev, void *y_local_dev, void *stream);
 int htool_distributed_matmat_device(htool_distributed *d, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream);
+/* The TRANSPOSED product with the same distribution (lib/htool's distributed operator has it; the reference's Python surface only
+ * ever passes 'N', distributed_operator.hpp:23-65): y = op(A) x with op = transpose ('T') or conjugate transpose ('C'; 'T' for
+ * real operators).  Every rank passes ITS slice of x -- the rows it owns: target partition `rank`, cluster numbering -- and
+ * receives ITS slice of y (source partition `rank`): the local block applies op to its rows (a full-length vector), the ranks'
+ * vectors are summed and dealt out by ONE reduce-scatter (htool_comm.reduce_scatter_device; padded slices unless the source
+ * partition is even and mu = 1), all on `stream`. */
+int htool_distributed_matmat_device_trans(htool_distributed *d, char trans, const void *X_local_dev, int64_t ldx, void *Y_local_dev, int64_t ldy, int mu, void *stream);
 /* which exchange the device product of this operator uses: 0 none (one rank owns everything), 1 the communicator's
  * allgather_device straight into the contiguous vector (equal slices, one column), 2 the same on padded slices followed by
  * the compaction kernel, 3 / 4 = 1 / 2 staged through the host (no allgather_device); -1: no device exchange possible (the

@@ -106,6 +106,33 @@ def main():
                         Hl.matmat_device(x_full.data_ptr(), ns, y_ref.data_ptr(), t_loc.get_size(), mu, 1, stream)
                         torch.cuda.synchronize()
                         assert torch.equal(y_ref, y_loc[:, : t_loc.get_size()]), (name, eps, force_padded, cplx, mu)
+                    # (2b) the TRANSPOSED product with the same distribution: x given by the rows each rank owns, y received by source
+                    # slices; one reduce-scatter inside the library.  Against exact entries: the kernels are functions of the distance,
+                    # (A^T w)[j] = sum_i K(s_j, t_i) w_i; 'C' conjugates A.
+                    t_sizes = [tcl.get_cluster_on_partition(q).get_size() for q in range(world)]
+                    t_offs = [tcl.get_cluster_on_partition(q).get_offset() for q in range(world)]
+                    nt = tp.shape[1]
+                    for mu, tr in ((1, "T"), (3, "C" if cplx else "T")):
+                        rs = np.random.RandomState(11 + mu)
+                        Wu = rs.rand(mu, nt) + (1j * rs.rand(mu, nt) if cplx else 0)   # USER numbering of the target points
+                        Wc = Wu[:, tperm]
+                        mine_t, mine_s = t_sizes[rank], s_sizes[rank]
+                        ldx, ldy = mine_t + 2, mine_s + 4
+                        w_loc = torch.full((mu, ldx), float("nan"), dtype=dt, device="cuda")
+                        w_loc[:, :mine_t] = torch.from_numpy(np.ascontiguousarray(Wc[:, t_offs[rank]: t_offs[rank] + mine_t])).cuda()
+                        z_loc = torch.zeros(mu, ldy, dtype=dt, device="cuda")
+                        op.matmat_device_trans(tr, w_loc.data_ptr(), ldx, z_loc.data_ptr(), ldy, mu, stream)
+                        torch.cuda.synchronize()
+                        gotz = z_loc[:, :mine_s].cpu().numpy()
+                        assert not np.isnan(gotz).any()
+                        cols = sperm[s_offs[rank]: s_offs[rank] + mine_s]
+                        for c in range(mu):
+                            win = np.conj(Wu[c]) if tr == "C" else Wu[c]
+                            ze = O.dense_matvec(kind, sp, tp, win, par, rows=cols)
+                            if tr == "C":
+                                ze = np.conj(ze)
+                            e2 = comm.allreduce(np.array([np.linalg.norm(gotz[c] - ze) ** 2, np.linalg.norm(ze) ** 2]), op=mpi4py.MPI.SUM)
+                            assert np.sqrt(e2[0] / e2[1]) < eps, (name, eps, force_padded, cplx, mu, tr, c, np.sqrt(e2[0] / e2[1]))
                     # (3) the replicated-vector API of the reference on the same operator agrees
                     if not cplx and x_user is not None:
                         y_rep = op * x_user

@@ -82,7 +82,7 @@ def test_c_abi_end_to_end(built, oracle):
 
 class HtoolComm(ctypes.Structure):
     _fields_ = [("rank", ctypes.c_int), ("size", ctypes.c_int), ("ctx", ctypes.c_void_p), ("allgatherv", ctypes.c_void_p), ("rccl", ctypes.c_void_p),
-                ("allgather_device", ctypes.c_void_p)]
+                ("allgather_device", ctypes.c_void_p), ("reduce_scatter_device", ctypes.c_void_p)]
 
 
 @pytest.mark.parametrize("padded", [False, True])
@@ -147,6 +147,19 @@ def test_c_abi_distributed_device_product_with_rccl_communicator(built, oracle, 
         yc[perm] = Yc[c]
         ye = O.dense_matvec(O.K_LAPLACE, points, points, X[c])
         assert np.linalg.norm(yc - ye) / np.linalg.norm(ye) < 1e-5
+    # the transposed product with the same distribution (one rank: the reduce-scatter is ncclReduceScatter on one chunk)
+    assert comm.reduce_scatter_device
+    dZ = dev_buffer(Xc.nbytes)
+    assert L.htool_distributed_matmat_device_trans(dist, ctypes.c_char(b"T"), dX, ctypes.c_int64(N), dZ, ctypes.c_int64(N), mu, None) == 0, L.htool_last_error()
+    assert hip.hipDeviceSynchronize() == 0
+    Zc = np.zeros_like(Xc)
+    assert hip.hipMemcpy(Zc.ctypes.data_as(ctypes.c_void_p), dZ, ctypes.c_size_t(Xc.nbytes), 2) == 0
+    for c in range(mu):
+        zc = np.zeros(N)
+        zc[perm] = Zc[c]
+        ze = O.dense_matvec(O.K_LAPLACE, points, points, X[c])   # (the Laplace kernel matrix is symmetric)
+        assert np.linalg.norm(zc - ze) / np.linalg.norm(ze) < 1e-5
+    hip.hipFree(dZ)
     # replicated-vector host API over the same communicator (distributed_operator.hpp:23-37)
     yh = np.zeros(N)
     assert L.htool_distributed_matvec(dist, X[0].ctypes, yh.ctypes) == 0, L.htool_last_error()
@@ -258,7 +271,7 @@ def test_c_abi_rank_r_of_eight_with_the_host_languages_own_device_allgather(buil
         return 0
 
     hook = ALLGATHER_DEVICE_FN(allgather_device)
-    comm = HtoolComm(rank, P, None, None, None, ctypes.cast(hook, ctypes.c_void_p))
+    comm = HtoolComm(rank, P, None, None, None, ctypes.cast(hook, ctypes.c_void_p), None)
     assert L.htool_distributed_create_default(gen, root, root, ctypes.byref(prm), ctypes.byref(comm), ctypes.byref(dist)) == 0, L.htool_last_error()
     parts = []
     for p in range(P):
@@ -319,7 +332,7 @@ def test_c_abi_rank_r_of_eight_with_the_host_languages_own_device_allgather(buil
     # a failing hook is reported, not ignored
     state["slices"] = None
     bad = ALLGATHER_DEVICE_FN(lambda *a: 1)
-    comm2 = HtoolComm(rank, P, None, None, None, ctypes.cast(bad, ctypes.c_void_p))
+    comm2 = HtoolComm(rank, P, None, None, None, ctypes.cast(bad, ctypes.c_void_p), None)
     dist2 = ctypes.c_void_p()
     assert L.htool_distributed_create_default(gen, root, root, ctypes.byref(prm), ctypes.byref(comm2), ctypes.byref(dist2)) == 0, L.htool_last_error()
     d_x, d_y = dev(np.zeros(pad)), dev(np.zeros(pad))
