@@ -584,8 +584,8 @@ static DenseFactor *factor_of(htool_hmatrix *h, int kind, char uplo) {
     else { f->ar.resize((size_t)n * n); densify(H, f->ar.data(), 1); if (kind == 1) lu_factor(n, f->ar, f->piv); else chol_factor(n, f->ar, uplo); }
     return f.release();
 }
-static void factorise(htool_hmatrix *h, int kind, char uplo, double shift) {
-    if (factor_on_device(h->H)) {
+static void factorise(htool_hmatrix *h, int kind, char uplo, double shift, bool device_only = false) {
+    if (device_only || factor_on_device(h->H)) {
         log_message(LOG_WARNING, strprintf("%s: dense fallback on the device (a dense copy of the operator is factorised by the dense solver library; hierarchical LU is not part of this engine)",
                                            kind == 1 ? "lu_factorization" : "cholesky_factorization"));
         DeviceDenseFactor *f = device_dense_factor(h->H, kind, uplo, shift);
@@ -609,8 +609,7 @@ int htool_hmatrix_lu_factorization(htool_hmatrix *h) {
 }
 int htool_hmatrix_lu_factorization_shifted(htool_hmatrix *h, double shift) {
     API_BEGIN
-    HM_CHECK(factor_on_device(h->H), "lu_factorization_shifted: device path only (operators beyond 20000 unknowns, partition-built blocks, or HTOOL_DENSE_FACTOR=device)");
-    factorise(h, 1, 'N', shift);
+    factorise(h, 1, 'N', shift, true); // (an extension of the device path: always there, whatever the size)
     API_END
 }
 int htool_hmatrix_cholesky_factorization(htool_hmatrix *h, char uplo) {

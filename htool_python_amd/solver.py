@@ -166,20 +166,7 @@ class DenseBlockLU:
         if n != m:
             raise RuntimeError("DenseBlockLU: the diagonal block is not square")
         self.H, self.n = block_hmatrix, n
-        if shift != 0.0:
-            block_hmatrix.lu_factorization_shifted(float(shift))
-        else:
-            import os
-
-            old = os.environ.get("HTOOL_DENSE_FACTOR")
-            os.environ["HTOOL_DENSE_FACTOR"] = "device"  # (also for blocks below the host fallback's 20 000: the solve must be on the device)
-            try:
-                block_hmatrix.lu_factorization()
-            finally:
-                if old is None:
-                    os.environ.pop("HTOOL_DENSE_FACTOR", None)
-                else:
-                    os.environ["HTOOL_DENSE_FACTOR"] = old
+        block_hmatrix.lu_factorization_shifted(float(shift))  # (the device path of the dense fallback, whatever the size: the solve must be on the device)
 
     @staticmethod
     def fits(n, is_complex, fraction=0.35):
