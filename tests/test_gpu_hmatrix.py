@@ -645,3 +645,53 @@ def test_grouped_phase_a_equals_per_tile_scheme(built, oracle, monkeypatch, case
     if world == 1:
         ye = O.dense_matvec(O.K_HELMHOLTZ if cplx else O.K_LAPLACE, T, S, x, 5.0 if cplx else 0.0)
         assert np.linalg.norm(ys[0] - ye) / np.linalg.norm(ye) < 1e-5
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,restart", [(5000, 12), (70001, 40), (300, 150)])
+def test_gmres_device_kernels_match_the_textbook_history(built, cplx, n, restart):
+    """The GPU path of krylov.gmres -- three launches of the library per step (two fused Gram-Schmidt passes, htool_krylov_project,
+    and the tail, htool_krylov_finish_step) -- on a dense operator living on the device: residual history equal to a textbook GMRES
+    (numpy, modified Gram-Schmidt + explicit least squares) to 1e-11 of the first residual, true residual equal to the last
+    estimate, lockstep block of right-hand sides equal to the single solves, bitwise repeatable (fixed-order sums).  Sizes: several
+    workgroups per vector with a ragged last one (70 001 = 136 x 512 + 369), one workgroup (300) with more basis vectors than rows of it."""
+    import torch
+
+    from htool_python_amd import krylov
+    from htool_python_amd.krylov import gmres
+    from tests.test_krylov_cpu import _reference_gmres_history
+
+    rng = np.random.RandomState(3)
+    if n <= 5000:
+        A = rng.rand(n, n) + (1j * rng.rand(n, n) if cplx else 0) + n * 0.06 * np.eye(n)
+        At = torch.from_numpy(A).cuda()
+        apply = lambda v: At @ v  # noqa: E731
+        Anp = A
+    else:  # a banded operator applied without forming it: diagonal + two shifted copies
+        d0 = 2.0 + rng.rand(n) + (0.3j * rng.rand(n) if cplx else 0)
+        d0t = torch.from_numpy(d0).cuda()
+        apply = lambda v: d0t * v + 0.4 * torch.roll(v, 1) + 0.3 * torch.roll(v, -7)  # noqa: E731
+        Anp = None
+    b = rng.rand(n) + (1j * rng.rand(n) if cplx else 0)
+    bt = torch.from_numpy(b).cuda()
+    iters = 2 * restart + 5 if n > 300 else 200
+    s0, r0 = krylov.HOST_SYNCS, krylov.REDUCE_CALLS
+    x, info = gmres(apply, bt, tol=0.0 if n > 300 else 1e-12, restart=restart, max_it=iters, reduce=lambda t: t)
+    if n > 300:
+        assert info["iterations"] == iters and krylov.REDUCE_CALLS - r0 == 2 * iters + info["restarts"] + 1 and krylov.HOST_SYNCS - s0 == iters + info["restarts"] + 1
+    got = np.array(info["residuals"])
+    if Anp is not None:
+        ref = _reference_gmres_history(Anp, b, restart, len(got))
+        assert np.max(np.abs(got - ref)) <= 1e-11 * ref[0] + 1e-15, np.max(np.abs(got - ref))
+    true_res = float(torch.linalg.norm(bt - apply(x)) / torch.linalg.norm(bt))
+    assert abs(true_res - got[-1]) <= 1e-9 + 1e-6 * got[-1]
+    x2, info2 = gmres(apply, bt, tol=0.0 if n > 300 else 1e-12, restart=restart, max_it=iters, reduce=lambda t: t)
+    assert torch.equal(x, x2) and info2["residuals"] == info["residuals"]      # fixed-order sums: bitwise repeatable
+    if n == 5000:  # a block of right-hand sides in lockstep = the single solves
+        B = torch.stack([bt, 2.0 * bt, torch.zeros_like(bt), torch.from_numpy(rng.rand(n) + (1j * rng.rand(n) if cplx else 0)).cuda()])
+        X, bi = gmres(lambda Z: Z @ At.t(), B, tol=1e-10, restart=restart, max_it=400)
+        for c in (0, 1, 3):
+            xc, ic = gmres(apply, B[c], tol=1e-10, restart=restart, max_it=400)
+            assert ic["iterations"] == bi["iterations_per_column"][c]
+            assert float(torch.linalg.norm(X[c] - xc)) <= 1e-9 * float(torch.linalg.norm(xc))
+        assert bi["iterations_per_column"][2] == 0 and float(torch.linalg.norm(X[2])) == 0.0
