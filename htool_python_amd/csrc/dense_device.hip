@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <memory>
+#include <mutex>
 
 #include "capi_internal.hpp"
 #include "device_internal.hpp"
@@ -41,8 +42,11 @@ struct SolverLib {
     rb_status (*dpotrf)(rb_handle, int, int64_t, double *, int64_t, int64_t *) = nullptr;
     rb_status (*dpotrs)(rb_handle, int, int64_t, int64_t, double *, int64_t, double *, int64_t) = nullptr;
     std::string error;
+    std::mutex mu;
     bool load() {
+        std::lock_guard<std::mutex> lock(mu); // (factorisations of several handles may start on several host threads)
         if (solver) return true;
+        error.clear();
         blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
         if (!blas) blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
         void *s = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);

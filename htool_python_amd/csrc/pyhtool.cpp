@@ -858,14 +858,6 @@ PYBIND11_MODULE(Htool, m) {
                                            (const void *)V, ld_basis, ld_rhs, (void *)stream));
         }, "W_ptr"_a, "ldw"_a, "n"_a, "mu"_a, "is_complex"_a, "h1_ptr"_a, "t2_ptr"_a, "j"_a, "mask_ptr"_a, "coef_ptr"_a, "scale"_a, "V_ptr"_a, "ld_basis"_a, "ld_rhs"_a, "stream"_a,
         "Tail of a GMRES step in one launch (htool_krylov_finish_step): second projection taken out, norm, scaling of w, coefficient row for the host");
-    m.def("krylov_project", [](std::uintptr_t V, long long ld_basis, long long ld_rhs, int n, int nvec, int mu, bool is_complex, std::uintptr_t W, long long ldw, std::uintptr_t h_in,
-                               bool with_ww, std::uintptr_t partial, std::uintptr_t counter, std::uintptr_t out, std::uintptr_t stream) {
-            check(htool_krylov_project((const void *)V, ld_basis, ld_rhs, n, nvec, mu, is_complex ? 1 : 0, (void *)W, ldw, (const void *)h_in, with_ww ? 1 : 0, (void *)partial,
-                                       (int *)counter, (void *)out, (void *)stream));
-        }, "V_ptr"_a, "ld_basis"_a, "ld_rhs"_a, "n"_a, "nvec"_a, "mu"_a, "is_complex"_a, "W_ptr"_a, "ldw"_a, "h_in_ptr"_a, "with_ww"_a, "partial_ptr"_a, "counter_ptr"_a, "out_ptr"_a, "stream"_a,
-        "One classical Gram-Schmidt pass in one launch (htool_krylov_project)");
-    m.def("krylov_max_basis", &htool_krylov_max_basis);
-    m.def("krylov_partial_elements", &htool_krylov_partial_elements);
     m.def("release_workspace", []() { return htool_release_workspace(); }, "Free the cached temporary device buffers of builds / recompressions; returns the bytes released");
     m.def("cluster_tiles", [](const PyCluster &c, int partition_number, int tile_max) {
             int n = htool_cluster_tiles(c.owner->root, partition_number, tile_max, nullptr, 0);

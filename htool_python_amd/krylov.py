@@ -144,18 +144,14 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
     m = max(1, int(restart))
     V = torch.empty(mu, m + 1, n, dtype=dt, device=dev)
     rb = _Readback(dev, dt, mu * (2 * m + 4))
-    finish_kernel = project_kernel = None
+    finish_kernel = None
     if dev.type == "cuda":
-        # the vector algebra of a step as THREE launches of the library (csrc/krylov_device.hip): two Gram-Schmidt passes (each one
-        # kernel: previous projection taken out, dot products, fixed-order sum by the last workgroup) and the tail (second projection
-        # taken out, norm, scaling, coefficient row) -- instead of four library GEMVs and ten one-element tensor operations
+        # the tail of a step as ONE launch of the library (csrc/krylov_device.hip: second projection taken out, norm, scaling,
+        # coefficient row) instead of a GEMV and ten one-element tensor operations; the two Gram-Schmidt dot-product passes
+        # stay library GEMVs (kernels of our own for them were slower: include/htool_mi355x.h)
         from . import Htool as _core
 
         finish_kernel = _core.krylov_finish_step
-        if m + 1 <= _core.krylov_max_basis():
-            project_kernel = _core.krylov_project
-            gs_partial = torch.empty(max(1, _core.krylov_partial_elements(n, m + 1, mu)), dtype=dt, device=dev)
-            gs_counter = torch.zeros(mu, dtype=torch.int32, device=dev)
     restarts = 0
     first = x0 is None
     while max(its) < max_it and not all(converged):
@@ -197,30 +193,17 @@ def gmres(apply, b, x0=None, tol=1e-6, restart=50, max_it=200, reduce=None, call
             else:
                 W.copy_(op(Z))
             Vj = V[:, : j + 1]
-            if project_kernel is not None:
-                st = torch.cuda.current_stream().cuda_stream
-                ld_rhs, ldw = (m + 1) * n, (W.stride(0) if mu > 1 else n)
-                h1 = torch.empty(mu, j + 1, dtype=dt, device=dev)
-                project_kernel(V.data_ptr(), n, ld_rhs, n, j + 1, mu, cplx, W.data_ptr(), ldw, 0, False, gs_partial.data_ptr(), gs_counter.data_ptr(), h1.data_ptr(), st)
-                allsum(h1)
-                t2 = torch.empty(mu, j + 2, dtype=dt, device=dev)  # [h2 ; w.w] of w with the first projection taken out
-                project_kernel(V.data_ptr(), n, ld_rhs, n, j + 1, mu, cplx, W.data_ptr(), ldw, h1.data_ptr(), True, gs_partial.data_ptr(), gs_counter.data_ptr(), t2.data_ptr(), st)
-                allsum(t2)
-                coef = torch.empty(mu, 2 * j + 4, dtype=dt, device=dev)
-                finish_kernel(W.data_ptr(), ldw, n, mu, cplx, h1.data_ptr(), t2.data_ptr(), j, mask_dev.data_ptr() if mask_dev is not None else 0, coef.data_ptr(), j + 1 < m,
-                              V.data_ptr(), n, ld_rhs, st)
-                return rb.post(coef)
             h1 = allsum(dots(Vj, W))
             subtract(W, Vj, h1)
             t2 = allsum(dots(V[:, : j + 2], W))  # [h2 ; w.w]: the last row of V[:, : j + 2] is W itself
             h2 = t2[:, : j + 1]
-            subtract(W, Vj, h2)
             if finish_kernel is not None:
-                # one launch of the library for the scalar tail: hn^2 = w.w - |h2|^2, w scaled by mask / hn, the coefficient row packed
+                # one launch of the library for the tail: w -= V h2, hn^2 = w.w - |h2|^2, w scaled by mask / hn, the coefficient row packed
                 coef = torch.empty(mu, 2 * j + 4, dtype=dt, device=dev)
                 finish_kernel(W.data_ptr(), W.stride(0) if mu > 1 else n, n, mu, cplx, h1.data_ptr(), t2.data_ptr(), j, mask_dev.data_ptr() if mask_dev is not None else 0,
-                              coef.data_ptr(), j + 1 < m, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+                              coef.data_ptr(), j + 1 < m, V.data_ptr(), n, (m + 1) * n, torch.cuda.current_stream().cuda_stream)
                 return rb.post(coef)
+            subtract(W, Vj, h2)
             ww = t2[:, j + 1].real if cplx else t2[:, j + 1]
             hn2 = ww - ((h2.real * h2.real + h2.imag * h2.imag) if cplx else h2 * h2).sum(dim=1)  # |w - V h2|^2 = w.w - |h2|^2
             if j + 1 < m:

@@ -339,26 +339,16 @@ int htool_distributed_exchange_kind(const htool_distributed *d, int mu);
 int htool_debug_compact_slices(const void *gathered_dev, void *x_full_dev, const int *counts, const int *displs, int P, int pad, int mu, int64_t ldx,
                                int is_complex, void *stream);
 
-/* ---- Krylov helpers (solver/solver.hpp:22-65: the reference hands the operator to HPDDM; this package runs its own GMRES on
+/* ---- Krylov helper (solver/solver.hpp:22-65: the reference hands the operator to HPDDM; this package runs its own GMRES on
  * device-resident vectors, htool_python_amd/krylov.py) -------------------------------------------------------------------
- * The vector algebra of an Arnoldi step with classical Gram-Schmidt applied twice, three launches on `stream` per step.
- * Basis layout: vector l of right-hand side c at V + c * ld_rhs + l * ld_basis (n entries each); w of right-hand side c at
- * W + c * ldw; coefficient type double or double[2].
- *
- * htool_krylov_project: ONE pass.  With h_in (mu x nvec) given, w -= sum_l h_in[l] v_l first (the projection of the previous
- * pass); then out[c][l] = <v_l, w> for l < nvec and, with_ww, out[c][nvec] = <w, w>.  partial: scratch of
- * htool_krylov_partial_elements(n, nvec_max, mu) entries of the coefficient type; counter: mu ints, zero before the first call
- * (the kernel leaves them zero).  The sums are added in a fixed order (no dependence on scheduling).  At most
- * htool_krylov_max_basis() vectors.  The caller reduces `out` over the ranks between the passes.
- *
- * htool_krylov_finish_step: the tail.  With h1 (j + 1 coefficients of the first pass) and t2 = [h2 | w.w] (j + 2 values of the
- * second), both reduced over the ranks: hn^2 = w.w - |h2|^2; w <- (w - sum_l h2[l] v_l) * mask[c] / sqrt(hn^2) in one sweep
- * (V NULL: no subtraction; scale = 0: no scaling; 0 when hn^2 <= 0; mask NULL = ones); the row [h1 | h2 | w.w | hn^2]
- * (2 j + 4 entries) written to coef + c * (2 j + 4) for the host to fetch. */
-int htool_krylov_project(const void *V_dev, int64_t ld_basis, int64_t ld_rhs, int n, int nvec, int mu, int is_complex, void *W_dev, int64_t ldw,
-                         const void *h_in_dev, int with_ww, void *partial_dev, int *counter_dev, void *out_dev, void *stream);
-int htool_krylov_max_basis(void);
-int64_t htool_krylov_partial_elements(int n, int nvec_max, int mu);
+ * The tail of an Arnoldi step with classical Gram-Schmidt applied twice, as ONE launch on `stream`.  Basis layout: vector l of
+ * right-hand side c at V + c * ld_rhs + l * ld_basis (n entries each); w of right-hand side c at W + c * ldw; coefficient
+ * type double or double[2].  With h1 (j + 1 coefficients of the first pass) and t2 = [h2 | w.w] (j + 2 values of the second),
+ * both reduced over the ranks: hn^2 = w.w - |h2|^2; w <- (w - sum_l h2[l] v_l) * mask[c] / sqrt(hn^2) in one sweep (V NULL: no
+ * subtraction -- the caller has taken the projection out already; scale = 0: no scaling; 0 when hn^2 <= 0; mask NULL = ones);
+ * the row [h1 | h2 | w.w | hn^2] (2 j + 4 entries) written to coef + c * (2 j + 4) for the host to fetch.
+ * (Round 3 also had the two Gram-Schmidt passes as kernels of this library; the BLAS library's GEMVs were faster -- 0.69 against
+ * 0.72 ms per iteration at 62 500 rows, 5.9 against 6.4 ms at 500 000 -- and stayed.) */
 int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_complex, const void *h1_dev, const void *t2_dev, int j, const double *mask_dev,
                              void *coef_dev, int scale, const void *V_dev, int64_t ld_basis, int64_t ld_rhs, void *stream);
 

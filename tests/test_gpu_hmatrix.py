@@ -650,11 +650,11 @@ def test_grouped_phase_a_equals_per_tile_scheme(built, oracle, monkeypatch, case
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("n,restart", [(5000, 12), (70001, 40), (300, 150)])
 def test_gmres_device_kernels_match_the_textbook_history(built, cplx, n, restart):
-    """The GPU path of krylov.gmres -- three launches of the library per step (two fused Gram-Schmidt passes, htool_krylov_project,
-    and the tail, htool_krylov_finish_step) -- on a dense operator living on the device: residual history equal to a textbook GMRES
+    """The GPU path of krylov.gmres -- library GEMVs for the two Gram-Schmidt passes and ONE launch of this library for the tail
+    (htool_krylov_finish_step: second projection taken out, norm, scaling, coefficient row) -- on a dense operator living on the device: residual history equal to a textbook GMRES
     (numpy, modified Gram-Schmidt + explicit least squares) to 1e-11 of the first residual, true residual equal to the last
-    estimate, lockstep block of right-hand sides equal to the single solves, bitwise repeatable (fixed-order sums).  Sizes: several
-    workgroups per vector with a ragged last one (70 001 = 136 x 512 + 369), one workgroup (300) with more basis vectors than rows of it."""
+    estimate, lockstep block of right-hand sides equal to the single solves, repeatable.  Sizes: several workgroups per vector
+    with a ragged last one (70 001 = 136 x 512 + 369), one workgroup (300) with a long basis."""
     import torch
 
     from htool_python_amd import krylov
@@ -686,7 +686,7 @@ def test_gmres_device_kernels_match_the_textbook_history(built, cplx, n, restart
     true_res = float(torch.linalg.norm(bt - apply(x)) / torch.linalg.norm(bt))
     assert abs(true_res - got[-1]) <= 1e-9 + 1e-6 * got[-1]
     x2, info2 = gmres(apply, bt, tol=0.0 if n > 300 else 1e-12, restart=restart, max_it=iters, reduce=lambda t: t)
-    assert torch.equal(x, x2) and info2["residuals"] == info["residuals"]      # fixed-order sums: bitwise repeatable
+    assert torch.equal(x, x2) and info2["residuals"] == info["residuals"]      # no atomics anywhere: repeatable
     if n == 5000:  # a block of right-hand sides in lockstep = the single solves
         B = torch.stack([bt, 2.0 * bt, torch.zeros_like(bt), torch.from_numpy(rng.rand(n) + (1j * rng.rand(n) if cplx else 0)).cuda()])
         X, bi = gmres(lambda Z: Z @ At.t(), B, tol=1e-10, restart=restart, max_it=400)
