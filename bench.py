@@ -247,8 +247,11 @@ def main():
 
     class _Keep(logging.Handler):
         def emit(self, record):
-            if "native build timing" in record.getMessage():
-                build_log.append(record.getMessage())
+            msg = record.getMessage()
+            if "native build timing" in msg:
+                build_log.append(msg)
+            elif "H-matrix built" in msg and build_log:  # (the C-ABI call as a whole: tiles, the native build, its clean-up)
+                build_log[-1] += "; " + msg
 
     logging.getLogger("Htool").addHandler(_Keep())
     logging.getLogger("Htool").setLevel(logging.INFO)
@@ -295,8 +298,10 @@ def main():
         else:
             approx, op_ = None, None
             H_ = builder.build(gen, cluster, cluster, -1)
+        t_call = time.time() - t0
         torch.cuda.synchronize()
-        return approx, op_, H_, time.time() - t0, (build_log[-1] if build_log else None)
+        t_all = time.time() - t0
+        return approx, op_, H_, t_all, ((build_log[-1] + f"; builder.build() returned after {t_call:.3f} s, device idle after {t_all:.3f} s") if build_log else None)
 
     # FIRST build of the process, nothing warmed or pre-conditioned: code objects of the build kernels are loaded, streams created,
     # every byte of VRAM the build uses is handed out (and wiped) by the driver for the first time -- build_cold_s

@@ -25,6 +25,8 @@
 #include <atomic>
 #include <cstring>
 #include <exception>
+#include <array>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <thread>
