@@ -268,30 +268,44 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     D->rhs_cap = nr;
 }
 
-// ---- sixteen right-hand sides per sweep on the matrix cores (operators that store both triangles) ----
+// ---- sixteen right-hand sides per sweep on the matrix cores ----
+// the partial sums a reduction pass adds, as index ranges of the coefficient workspace (read back from its tile table)
+static std::vector<Reduce16> reduce16_items(DeviceHMatrix *D, const GTile *tiles, int n) {
+    std::vector<Reduce16> items;
+    if (!n) return items;
+    std::vector<GTile> t((size_t)n);
+    HIP_OK(hipMemcpy(t.data(), tiles, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
+    for (const GTile &x : t) {
+        GSeg sg;
+        HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
+        Reduce16 r;
+        r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)D->esize;
+        r.out_base = x.out_begin;
+        r.ld = sg.ld_last; r.nrows = sg.nrows_t; r.ncols = sg.ncols;
+        for (r.row0 = 0; r.row0 < r.nrows; r.row0 += 16) items.push_back(r); // one work item per 16 rows
+    }
+    return items;
+}
+
 static void ensure_w16(DeviceHMatrix *D) {
     if (D->W16) return;
     drop_product_graph(D);
     void *w = nullptr;
     HIP_OK(dev_malloc(&w, (size_t)D->W_elems * 16 * D->esize));
     HIP_OK(hipMemset(w, 0, (size_t)D->W_elems * 16 * D->esize));
-    // the partial sums phase A2 reduces, as index ranges of the coefficient workspace (read back from the A2 tables)
-    std::vector<Reduce16> items;
-    if (D->nA2) {
-        std::vector<GTile> t((size_t)D->nA2);
-        HIP_OK(hipMemcpy(t.data(), D->tilesA2, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
-        for (const GTile &x : t) {
-            GSeg sg;
-            HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
-            Reduce16 r;
-            r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)D->esize;
-            r.out_base = x.out_begin;
-            r.ld = sg.ld_last; r.nrows = sg.nrows_t; r.ncols = sg.ncols;
-            for (r.row0 = 0; r.row0 < r.nrows; r.row0 += 16) items.push_back(r); // one work item per 16 rows
-        }
-    }
+    const std::vector<Reduce16> items = reduce16_items(D, D->tilesA2, D->nA2); // phase A2
     D->red16 = upload(items);
     D->n_red16 = (int)items.size();
+    if (D->one_triangle || D->transposable) { // the tables of the fused / transposed sweeps, 16 wide
+        const std::vector<Reduce16> zitems = reduce16_items(D, D->tilesZ, D->nZ);
+        D->redz16 = upload(zitems);
+        D->n_redz16 = (int)zitems.size();
+        HIP_OK(dev_malloc(&D->ycl16, (size_t)std::max<long long>(D->ycl_stride, 1) * 16 * D->esize));
+        if (D->transposable) {
+            HIP_OK(dev_malloc(&D->xt16, (size_t)std::max<long long>(D->xt_stride, 1) * 16 * D->esize));
+            HIP_OK(hipMemset(D->xt16, 0, (size_t)std::max<long long>(D->xt_stride, 1) * 16 * D->esize));
+        }
+    }
     D->W16 = w;
 }
 
@@ -316,6 +330,52 @@ static void launch_sweep16(DeviceHMatrix *D, const T *x, long long x_stride, T *
     if (timing) D->nprod++;
 }
 
+// one-triangle storage, sixteen right-hand sides: the passes of launch_sweep's fused branch, on the matrix cores
+template <typename T>
+static void launch_sweep16_sym(DeviceHMatrix *D, const T *x, long long x_stride, T *y, long long y_stride, int nr, int numbering, hipStream_t st) {
+    constexpr bool CPLX = sizeof(T) == 16;
+    T *W16 = (T *)D->W16;
+    const int Ns = D->n_source;
+    const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
+    const int cj = D->conj_transposed ? 1 : 0;
+    hipEvent_t *ev = D->pev[D->nprod % DeviceHMatrix::RING];
+    const bool timing = D->phase_timing;
+    if (timing) HIP_OK(hipEventRecord(ev[0], st));
+    if (Ns) hipLaunchKernelGGL(gather_x16_kernel<T>, dim3((unsigned)((Ns + 63) / 64)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_s : (const int *)nullptr, W16, Ns, nr);
+    if (timing) HIP_OK(hipEventRecord(ev[1], st));
+    if (D->nA) hipLaunchKernelGGL(tile_gemm_tall16<CPLX>, dim3(D->nA), dim3(256), 0, st, D->tilesA, D->segs, (double *)W16);
+    if (timing) HIP_OK(hipEventRecord(ev[2], st));
+    if (D->n_red16) hipLaunchKernelGGL(reduce_partials16_kernel<T>, dim3(D->n_red16), dim3(256), 0, st, (const Reduce16 *)D->red16, W16);
+    if (timing) HIP_OK(hipEventRecord(ev[3], st));
+    if (D->nB) hipLaunchKernelGGL((tile_gemm_wide16_sym<CPLX, true>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const double *)W16, (double *)W16, (double *)D->ycl16,
+                                  (const double *)W16, cj);
+    if (D->n_redz16) hipLaunchKernelGGL(reduce_partials16_kernel<T>, dim3(D->n_redz16), dim3(256), 0, st, (const Reduce16 *)D->redz16, W16);
+    if (D->nAT) hipLaunchKernelGGL(tile_gemm_tall16_transposed<CPLX>, dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const double *)W16, (double *)D->ycl16, cj);
+    if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym16_kernel<T>, dim3(D->n_zd_tiles), dim3(256), 0, st, (const T *)D->ycl16, (const T *)W16, D->zd_ptr, D->zd_woff, D->zd_rows,
+                                          out_user ? D->perm_t : (const int *)nullptr, y, nr, y_stride);
+    if (timing) HIP_OK(hipEventRecord(ev[4], st));
+    HIP_OK(hipGetLastError());
+    if (timing) D->nprod++;
+}
+
+// y = H^T x (conj: H^H x) for sixteen right-hand sides (launch_sweep_T on the matrix cores)
+template <typename T>
+static void launch_sweep16_T(DeviceHMatrix *D, const T *x, long long x_stride, T *y, long long y_stride, int nr, int numbering, bool conj, hipStream_t st) {
+    constexpr bool CPLX = sizeof(T) == 16;
+    T *W16 = (T *)D->W16, *XT16 = (T *)D->xt16;
+    const bool in_user = numbering == 0 || numbering == 2, out_user = numbering == 0 || numbering == 3;
+    const int cj = conj ? 1 : 0;
+    if (D->row_size) hipLaunchKernelGGL(gather_x16_kernel<T>, dim3((unsigned)((D->row_size + 63) / 64)), dim3(256), 0, st, x, x_stride, in_user ? D->perm_t + D->row_off : (const int *)nullptr, XT16, D->row_size, nr);
+    const T *Xrows = XT16 - (long long)D->row_off * 16; // (the row tiles carry target positions of the whole cluster tree)
+    if (D->nB) hipLaunchKernelGGL((tile_gemm_wide16_sym<CPLX, false>), dim3(D->nB), dim3(256), 0, st, D->tilesB_cluster, D->segs, (const double *)W16, (double *)W16, (double *)nullptr, (const double *)Xrows, cj);
+    if (D->n_redz16) hipLaunchKernelGGL(reduce_partials16_kernel<T>, dim3(D->n_redz16), dim3(256), 0, st, (const Reduce16 *)D->redz16, W16);
+    HIP_OK(hipMemsetAsync(D->ycl16, 0, (size_t)std::max<long long>(D->ycl_stride, 1) * 16 * sizeof(T), st));
+    if (D->nAT) hipLaunchKernelGGL(tile_gemm_tall16_transposed<CPLX>, dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const double *)W16, (double *)D->ycl16, cj);
+    if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym16_kernel<T>, dim3(D->n_zd_tiles), dim3(256), 0, st, (const T *)D->ycl16, (const T *)W16, D->zd_ptr, D->zd_woff, D->zd_rows,
+                                          out_user ? D->perm_s : (const int *)nullptr, y, nr, y_stride);
+    HIP_OK(hipGetLastError());
+}
+
 static bool mfma_sweep_enabled() {
     const char *v = getenv("HTOOL_MULTI_RHS_KERNEL"); // "valu": the 8-wide VALU sweeps for every count (A/B comparisons, tests)
     return !(v && std::string(v) == "valu");
@@ -329,7 +389,13 @@ static void launch_product(DeviceHMatrix *D, const void *X, long long x_stride, 
         const int left = mu - done;
         const T *x = (const T *)X + (long long)done * x_stride;
         T *y = (T *)Y + (long long)done * y_stride;
-        if (D->one_triangle) { // fused sweeps take up to four right-hand sides
+        if (D->one_triangle) { // fused sweeps: sixteen right-hand sides on the matrix cores, up to four on the vector units
+            if (left > 8 && D->W16 && D->ycl16) {
+                const int nr = std::min(left, 16);
+                launch_sweep16_sym<T>(D, x, x_stride, y, y_stride, nr, numbering, st);
+                done += nr;
+                continue;
+            }
             if (left >= 4) { launch_sweep<Ops, 4>(D, x, x_stride, y, y_stride, numbering, st); done += 4; }
             else if (left >= 2) { launch_sweep<Ops, 2>(D, x, x_stride, y, y_stride, numbering, st); done += 2; }
             else { launch_sweep<Ops, 1>(D, x, x_stride, y, y_stride, numbering, st); done += 1; }
@@ -393,6 +459,12 @@ static void launch_product_T(DeviceHMatrix *D, const void *X, long long x_stride
         const int left = mu - done;
         const T *x = (const T *)X + (long long)done * x_stride;
         T *y = (T *)Y + (long long)done * y_stride;
+        if (left > 8 && D->W16 && D->xt16) {
+            const int nr = std::min(left, 16);
+            launch_sweep16_T<T>(D, x, x_stride, y, y_stride, nr, numbering, conj, st);
+            done += nr;
+            continue;
+        }
         if (left >= 4) { launch_sweep_T<Ops, 4>(D, x, x_stride, y, y_stride, numbering, conj, st); done += 4; }
         else if (left >= 2) { launch_sweep_T<Ops, 2>(D, x, x_stride, y, y_stride, numbering, conj, st); done += 2; }
         else { launch_sweep_T<Ops, 1>(D, x, x_stride, y, y_stride, numbering, conj, st); done += 1; }
@@ -418,6 +490,10 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
     if (trans != 'N') {
         if (!H.transposable) device_make_transposable(const_cast<HMatrix &>(H)); // (a cache of tables, made under the handle's lock)
         const int need_t = mu >= 4 ? 4 : mu >= 2 ? 2 : 1;
+        if (mu > 8 && !D->W16 && mfma_sweep_enabled()) {
+            HIP_OK(hipStreamSynchronize(st));
+            ensure_w16(D);
+        }
         if (need_t > D->rhs_cap) {
             HIP_OK(hipStreamSynchronize(st));
             if (D->is_complex) ensure_rhs_capacity<double2>(D, need_t);
@@ -428,7 +504,7 @@ void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, v
         return;
     }
     const int need = D->one_triangle ? (mu >= 4 ? 4 : mu >= 2 ? 2 : 1) : (mu >= 8 ? 8 : mu >= 4 ? 4 : mu >= 2 ? 2 : 1);
-    if (mu > 8 && !D->one_triangle && !D->W16 && mfma_sweep_enabled()) {
+    if (mu > 8 && !D->W16 && mfma_sweep_enabled()) {
         HIP_OK(hipStreamSynchronize(st));
         ensure_w16(D);
     }
@@ -582,7 +658,7 @@ void device_free(DeviceHMatrix *D) {
         if (B.zidxB) (void)hipFree(B.zidxB);
         if (B.tidxA) (void)hipFree(B.tidxA);
     }
-    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16, D->xt})
+    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16, D->xt, D->redz16, D->ycl16, D->xt16})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
                     (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord, (void *)D->tilesB_split, D->ypart})

@@ -119,6 +119,11 @@ struct DeviceHMatrix {
     void *W16 = nullptr;
     void *red16 = nullptr;
     int n_red16 = 0;
+    // ... and of one-triangle storage / the transposed product: the sums of the transposed partials, y accumulated in the
+    // W16 layout ([position][16]) and, for the transposed product, x gathered by row position
+    void *redz16 = nullptr;
+    int n_redz16 = 0;
+    void *ycl16 = nullptr, *xt16 = nullptr;
     void *W = nullptr;
     long long W_elems = 0;   // elements of ONE coefficient workspace; W holds rhs_cap of them back to back
     int rhs_cap = 0;

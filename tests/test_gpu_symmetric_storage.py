@@ -245,3 +245,76 @@ def test_one_triangle_with_separately_built_identical_trees(built, oracle):
     H2 = Htool.HMatrixTreeBuilder(1e-4, 10.0, "S", "L").build(Htool.NativeGenerator("inv_delta", pts, pts, 0.1), tcl, other)
     assert not H2.is_one_triangle()
     assert np.linalg.norm(H2 * x - y_exact) / np.linalg.norm(y_exact) < 1e-4
+
+
+@pytest.mark.parametrize("case", ["leaf10_L", "leaf48_U", "leaf100_L", "leaf300_U", "multi_batch", "complex_S", "hermitian", "copy"])
+def test_one_triangle_sixteen_wide_sweep(built, oracle, case, monkeypatch):
+    """Sixteen right-hand sides per fused sweep on the matrix cores (the panels transposed by MFMAs with selection matrices
+    for their second use): column by column against the single-vector products (<= 1e-13 relative), the sweeps of four on
+    the vector units and the exact dense operator; row tiles of <= 32, <= 64, <= 128 rows and clusters cut into several
+    tiles, several pack batches (segments per tile), complex symmetric and Hermitian storage, deep copies."""
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    np.random.seed(5)
+    if case == "hermitian":
+        n, leaf, eps = 2000, 25, 1e-5
+        pts = O.points_in_sphere(n)
+        theta = 3.0 * pts[0]
+
+        class HermitianGenerator(Htool.ComplexVirtualGenerator):
+            def build_submatrix(self, J, K, mat):
+                mat[:, :] = np.exp(1j * (theta[J][:, None] - theta[K][None, :])) * O.kernel_block(0, pts[:, J], pts[:, K], 0.1)
+
+        A = np.exp(1j * (theta[:, None] - theta[None, :])) * O.kernel_block(0, pts, pts, 0.1)
+        b = Htool.ComplexHMatrixTreeBuilder(eps, 10.0, "H", "U")
+        b.set_symmetric_storage(True)
+        cl = cluster_of(pts, leaf)
+        gen = HermitianGenerator()
+        H = b.build(gen, cl, cl)
+        exact = lambda X: A @ X
+        cplx = True
+    elif case == "complex_S":
+        n, leaf, eps = 4000, 40, 1e-4
+        pts = O.points_in_sphere(n)
+        H, cl, _ = _sym_build(pts, 2, 5.0, eps, 10.0, leaf, "L", complex_=True)
+        exact = lambda X: O.dense_matvec(2, pts, pts, X, 5.0)
+        cplx = True
+    else:
+        leaf = {"leaf10_L": 10, "leaf48_U": 48, "leaf300_U": 300}.get(case, 100)
+        n = {10: 3000, 48: 4000, 300: 7001}.get(leaf, 9000)
+        eps = 1e-5
+        if case == "multi_batch":
+            n = 20000
+            monkeypatch.setenv("HTOOL_BUILD_ARENA_MB", "40")
+        pts = O.points_in_sphere(n)
+        H, cl, _ = _sym_build(pts, 1, 0.0, eps, 10.0, leaf, case[-1] if case[-1] in "LU" else "L")
+        exact = lambda X: O.dense_matvec(1, pts, pts, X, 0.0)
+        cplx = False
+    assert H.is_one_triangle()
+    if case == "copy":
+        H0 = H
+        X0 = np.asfortranarray(np.random.rand(n, 16))
+        Y0 = H0 @ X0
+        H = copy.deepcopy(H0)
+        del H0
+        assert np.array_equal(H @ X0, Y0)
+    for mu in (9, 16, 37):
+        X = np.random.rand(n, mu)
+        if cplx:
+            X = X + 1j * np.random.rand(n, mu)
+        X = np.asfortranarray(X)
+        Y = H @ X
+        assert np.array_equal(H @ X, Y)  # fixed summation order
+        for c in range(mu):
+            yc = H * np.ascontiguousarray(X[:, c])
+            assert np.linalg.norm(Y[:, c] - yc) <= 1e-13 * np.linalg.norm(yc), (case, mu, c)
+        Ye = exact(X)
+        assert np.linalg.norm(Y - Ye) / np.linalg.norm(Ye) < eps
+    # the same columns through the sweeps of four (vector units): equal to rounding, not bitwise (other order of the sums)
+    monkeypatch.setenv("HTOOL_MULTI_RHS_KERNEL", "valu")
+    H2 = copy.deepcopy(H)
+    Yv = H2 @ X
+    assert np.linalg.norm(Yv - Y) <= 1e-13 * np.linalg.norm(Y)
+    assert not np.array_equal(Yv, Y)

@@ -221,3 +221,60 @@ def test_transposed_product_after_recompression_and_after_reload(built, oracle, 
     z2 = H2.transposed_mul(w)
     assert _rel(z2, z1) < 1e-12
     assert abs(w @ (H2 * x) - z2 @ x) < 1e-10 * abs(w @ y1)
+
+
+@pytest.mark.parametrize("case", ["rect_leaf10", "rect_leaf64", "native_multi_batch", "complex", "partition"])
+def test_transposed_product_sixteen_wide(built, oracle, case, monkeypatch):
+    """Y = H^T X / H^H X for more than eight right-hand sides: one sweep of the panels on the matrix cores per sixteen columns
+    (operands transposed by MFMAs with selection matrices), against the sweeps of one column (<= 1e-13), the H-matrix's own
+    dense expansion and the adjoint identity; rectangular, several pack batches, complex ('T' and 'C'), a row-partition share."""
+    import Htool
+    from tests.helpers import ComplexNumpyGenerator, NumpyGenerator, cluster_of
+
+    O = oracle
+    rng = np.random.RandomState(7)
+    trans = ("T",)
+    if case.startswith("rect"):
+        leaf = int(case[9:])
+        T, S = rng.random_sample((3, 1500)), rng.random_sample((3, 700)) + np.array([[0.3], [0.0], [0.0]])
+        H = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N").build(NumpyGenerator(T, S), cluster_of(T, leaf), cluster_of(S, leaf))
+        cplx = False
+    elif case == "native_multi_batch":
+        from htool_python_amd.workloads import points_in_sphere
+        monkeypatch.setenv("HTOOL_BUILD_ARENA_MB", "40")
+        T = S = points_in_sphere(20000, seed=5)
+        cl = cluster_of(T, 50)
+        H = Htool.HMatrixTreeBuilder(1e-4, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", T, S), cl, cl)
+        cplx = False
+    elif case == "complex":
+        T, S = rng.random_sample((3, 900)), rng.random_sample((3, 1300))
+        H = Htool.ComplexHMatrixTreeBuilder(1e-5, 10.0, "N", "N").build(ComplexNumpyGenerator(T, S, 5.0), cluster_of(T, 20), cluster_of(S, 20))
+        cplx = True
+        trans = ("T", "C")
+    else:  # the rows of one partition member against all columns
+        T = S = O.points_in_sphere(6000)
+        b = Htool.ClusterTreeBuilder()
+        b.set_maximal_leaf_size(60)
+        tcl = b.create_cluster_tree(T, 2, size_of_partition=3)
+        H = Htool.HMatrixTreeBuilder(1e-5, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", T, S), tcl, tcl, 1)
+        cplx = False
+    nt, ns = H.shape
+    for tr in trans:
+        for mu in (9, 16, 21):
+            X = rng.random_sample((nt, mu))
+            if cplx:
+                X = X + 1j * rng.random_sample((nt, mu))
+            X = np.asfortranarray(X)
+            Y = np.asarray(H.transposed_mul(X, tr))
+            assert Y.shape == (ns, mu)
+            assert np.array_equal(np.asarray(H.transposed_mul(X, tr)), Y)
+            for c in range(mu):
+                yc = H.transposed_mul(np.ascontiguousarray(X[:, c]), tr)
+                assert _rel(Y[:, c], yc) < 1e-13, (case, tr, mu, c)
+    # adjoint identity with the direct 16-wide sweep: <X, H Z> = <H^T X, Z>
+    Z = rng.random_sample((ns, 16)) + (1j * rng.random_sample((ns, 16)) if cplx else 0)
+    Z = np.asfortranarray(Z)
+    X = np.asfortranarray(X[:, :16])
+    lhs = np.sum(X * (H @ Z))
+    rhs = np.sum(np.asarray(H.transposed_mul(X, "T")) * Z)
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
