@@ -554,7 +554,8 @@ def main():
         bytes_b = ab["phase_b"] + (ab["phase_a"] if fused else 0)
         out["roofline"] = {
             "bound": "hbm",
-            "kernel": "tile_gemv_wide_sym + tile_gemv_tall_transposed (fused sweep of the stored triangle)" if fused else "tile_gemv_wide (phase B: U and dense panels)",
+            "kernel": (("tile_gemm_wide16_sym + tile_gemm_tall16_transposed" if args.rhs > 8 else "tile_gemv_wide_sym + tile_gemv_tall_transposed") + " (fused sweep of the stored triangle)") if fused
+                      else ("tile_gemm_wide16 (phase B: U and dense panels, 16 right-hand sides on the matrix cores)" if args.rhs > 8 else "tile_gemv_wide (phase B: U and dense panels)"),
             "achieved": (bytes_b / t_b / 1e9) if t_b else None,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

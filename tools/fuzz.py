@@ -144,6 +144,10 @@ def main(budget, seed, only_case=None, with_oracle=False):
             errT = np.linalg.norm(z[cols] - ze) / zscale
             ok = ok and z.shape == (ns,) and np.all(np.isfinite(z)) and errT < tol
             ok = ok and np.array_equal(H * x, y_ref)  # the direct product after the tables were written again
+            # ... and eleven columns of it: the 16-wide transposed sweep on the matrix cores
+            W16 = np.asfortranarray(np.stack([w * (1.0 + 0.1 * c) for c in range(11)], axis=1))
+            Z16 = np.asarray(H.transposed_mul(W16, "T"))
+            ok = ok and np.allclose(Z16[:, 0], z, rtol=1e-10, atol=1e-12 * zscale) and np.allclose(Z16[:, 10], 2.0 * z, rtol=1e-10, atol=1e-12 * zscale)
             lhs, rhs = np.sum(w * y_ref), np.sum(z * x)
             ok = ok and abs(lhs - rhs) <= 1e-9 * (abs(lhs) + np.linalg.norm(w) * np.linalg.norm(y_ref) * 1e-3)
             if recompress:
