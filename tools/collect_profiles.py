@@ -81,8 +81,14 @@ names = {"bench_rhs1": R + "_bench_1m_laplace_rhs1.json", "bench_rhs8": R + "_be
 names.update({"bench_125k": R + "_bench_125k_graph_replay.json", "bench_gmres50_62500_one_rank_rccl": R + "_gmres50_62500_one_rank_rccl.json",
               "bench_gmres50_500k_one_rank_rccl": R + "_gmres50_500k_one_rank_rccl.json", "bench_gloo2": R + "_rehearsal_gloo2_200k_inside_library.json",
               "bench_gloo3": R + "_rehearsal_gloo3_200k_inside_library.json"})
+names.update({"bench_sym_rhs16": R + "_bench_1m_laplace_sym_one_triangle_rhs16.json", "bench_trans_T_rhs16": R + "_bench_1m_laplace_transposed_rhs16.json",
+              "bench_helm_sym_rhs16": R + "_bench_c3_1m_helmholtz_sym_one_triangle_rhs16.json"})
 for src, dst in names.items():
     cp(os.path.join(F2, src + ".json"), dst)
+# the 16-wide one-triangle sweep under the profiler, the matrix-core rate its fused phase B is priced against, the fuzz run of the final code
+cp(first(os.path.join(F, "kt_sym16", "**", "*kernel_stats.csv")), R + "_bench_1m_laplace_sym_rhs16_kernel_stats.csv")
+cp(os.path.join(F, "bench_sym_rhs16_under_rocprof.json"), R + "_bench_1m_laplace_sym_rhs16_under_rocprof.json")
+cp(os.path.join(F, "mfma_f64_rate.txt"), R + "_mfma_f64_rate.txt")
 cp(os.path.join(F2, "dense_lu_62k.log"), R + "_dense_device_lu_62500.txt")
 # BASELINE config C3 under the profiler (kernel stats + the two PMC passes), and its build timeline
 cp(os.path.join(F, "bench_c3_under_rocprof.json"), R + "_bench_c3_1m_helmholtz_under_rocprof.json")
