@@ -450,12 +450,35 @@ int htool_hmatrix_matvec_device(const htool_hmatrix *h, const void *x_dev, void 
 } // extern "C"
 
 static void densify(const HMatrix &H, void *out, int user_numbering) {
-    // dense(H) = H * I, 64 unit vectors per call (8 sweeps of 8 right-hand sides); test-sized operators only
     const size_t es = H.is_complex ? 16 : 8;
     const int ns = H.col_size;
     const size_t nr = (size_t)(H.t_root == 0 ? H.tc->n_points : H.row_size);
     const int BS = 64;
-    if (H.s_root != 0 || H.local_numbering) user_numbering = 1; // local block: both sides are slices in cluster order already
+    const bool local = H.s_root != 0 || H.local_numbering; // local block: both sides are slices in cluster order already
+    // leaf by leaf on the device (device_expand.inc) when the dense copy fits there: every panel is read once; the permutation to
+    // the caller's numbering (columns; rows too when the operator covers the whole target cluster) is applied here
+    static const bool by_products = getenv("HTOOL_DENSE_EXPANSION") && std::string(getenv("HTOOL_DENSE_EXPANSION")) == "products";
+    if (!by_products && nr == (size_t)H.row_size) {
+        const bool permute_cols = user_numbering && !local, permute_rows = permute_cols && H.t_root == 0;
+        std::vector<char> tmp;
+        void *dst = out;
+        if (permute_cols) { tmp.resize(nr * (size_t)ns * es); dst = tmp.data(); }
+        if (device_to_dense_host(H, dst)) {
+            if (permute_cols) {
+                const long long ncol = ns;
+#pragma omp parallel for schedule(static)
+                for (long long j = 0; j < ncol; j++) {
+                    const char *src = tmp.data() + (size_t)j * nr * es;
+                    char *col = (char *)out + (size_t)H.sc->perm[H.col_off + j] * nr * es;
+                    if (!permute_rows) std::memcpy(col, src, nr * es);
+                    else for (size_t i = 0; i < nr; i++) std::memcpy(col + (size_t)H.tc->perm[H.row_off + i] * es, src + i * es, es);
+                }
+            }
+            return;
+        }
+    }
+    if (local) user_numbering = 1;
+    // dense(H) = H * I, 64 unit vectors per call (8 sweeps of 8 right-hand sides)
     std::vector<char> e((size_t)ns * BS * es, 0), col(nr * BS * es);
     const double one = 1.0, zero = 0.0;
     for (int j0 = 0; j0 < ns; j0 += BS) {

@@ -21,6 +21,7 @@ struct htool_hmatrix {
 };
 // dense_device.hip
 void device_to_dense_device(const hm::HMatrix &H, void *out_dev, long long ld, void *stream);
+bool device_to_dense_host(const hm::HMatrix &H, void *out);
 DeviceDenseFactor *device_dense_factor(const hm::HMatrix &H, int kind, char uplo, double shift);
 void device_dense_solve(const DeviceDenseFactor *f, char trans, void *B_dev, long long ldb, int mu, void *stream);
 void device_dense_solve_host(const hm::HMatrix &H, const DeviceDenseFactor *f, char trans, void *B, int mu);

@@ -95,10 +95,16 @@ __global__ void permute_rows_kernel(const T *src, T *dst, const int *perm, int n
 } // namespace
 
 // dense(H) into out_dev (column-major, leading dimension ld >= rows), cluster numbering of the rows and columns THIS operator
-// covers (its row slice / source slice for partition-built operators); enqueued on `stream`, returns after the last launch
+// covers (its row slice / source slice for partition-built operators): leaf by leaf (device_expand.inc); HTOOL_DENSE_EXPANSION=products
+// keeps the first form (products with unit vectors, 16 columns per sweep of all panels) for comparison
 void device_to_dense_device(const HMatrix &H, void *out_dev, long long ld, void *stream) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
+    static const bool by_products = getenv("HTOOL_DENSE_EXPANSION") && std::string(getenv("HTOOL_DENSE_EXPANSION")) == "products";
+    if (!by_products) {
+        device_expand_to_dense(const_cast<HMatrix &>(H), out_dev, ld, stream); // (uses the arena offsets of the block records as scratch, under the handle's lock)
+        return;
+    }
     HIP_OK(hipSetDevice(D->device));
     const size_t es = H.is_complex ? 16 : 8;
     const int ns = D->n_source, nr = D->row_size;
@@ -125,6 +131,31 @@ void device_to_dense_device(const HMatrix &H, void *out_dev, long long ld, void 
         throw;
     }
     (void)hipFree(X);
+}
+
+// the same into a HOST matrix (column-major rows x columns of the operator, cluster numbering); false: the dense copy does not fit the
+// device next to the operator (the caller falls back to products with unit vectors, 64 columns at a time)
+bool device_to_dense_host(const HMatrix &H, void *out) {
+    DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HIP_OK(hipSetDevice(D->device));
+    const size_t es = H.is_complex ? 16 : 8;
+    const size_t bytes = (size_t)H.row_size * (size_t)H.col_size * es;
+    if (bytes == 0) return true;
+    size_t free_b = 0, total_b = 0;
+    HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + ((size_t)2 << 30) > free_b) return false;
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    try {
+        device_to_dense_device(H, d, H.row_size, nullptr);
+        HIP_OK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+    } catch (...) {
+        (void)hipFree(d);
+        throw;
+    }
+    (void)hipFree(d);
+    return true;
 }
 
 struct DeviceDenseFactor {

@@ -817,4 +817,5 @@ void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *Bout) {
 
 #include "device_build.inc"
 #include "device_recompress.inc"
+#include "device_expand.inc"
 

@@ -169,6 +169,8 @@ void device_matvec_device(const HMatrix &H, const void *x_dev, void *y_dev, int 
 void device_matmat_device(const HMatrix &H, const void *X, long long x_stride, void *Y, long long y_stride, int mu, int numbering, void *stream, char trans = 'N');
 void device_matmat_host(const HMatrix &H, const void *X, int mu, void *Y, char trans = 'N');
 void device_make_transposable(HMatrix &H);
+// dense(H), leaf by leaf, into a device matrix (cluster numbering of the rows / columns the operator covers): device_expand.inc
+void device_expand_to_dense(HMatrix &H, void *out_dev, long long ld, void *stream);
 int64_t device_recompress(HMatrix &H, double eps);
 void device_clone(const HMatrix &src, HMatrix &dst);
 void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *B);

@@ -240,7 +240,7 @@ def test_graph_replay_then_other_buffers(built, oracle):
 @pytest.mark.parametrize("case", ["real", "complex", "spd_cholesky", "one_triangle"])
 def test_dense_factorisation_on_the_device(built, oracle, monkeypatch, case):
     """lu_factorization / lu_solve / cholesky_* (src/htool/hmatrix/hmatrix.hpp:58-94) through the DEVICE path of the dense fallback
-    (dense_device.hip: dense(H) expanded on the device by sweeps of 16 unit vectors, factorised by the dense solver library):
+    (dense_device.hip: dense(H) expanded on the device leaf by leaf, factorised by the dense solver library):
     forced here for a small operator (HTOOL_DENSE_FACTOR=device; operators beyond 20 000 unknowns and partition-built blocks take
     it by themselves).  Checks: the device expansion equals to_dense() (cluster numbering); A x = b and A^T x = b solved to the
     accuracy of the operator; several right-hand sides; errors for a missing factorisation."""
@@ -346,3 +346,93 @@ def test_one_level_preconditioner_at_the_per_gpu_block_of_c5(built, oracle):
     assert np.linalg.norm(xs - x_ref) / np.linalg.norm(x_ref) < 1e-6
     del solver, Hb
     Htool.release_workspace()
+
+
+@pytest.mark.parametrize("case", ["real", "complex", "one_triangle_L", "one_triangle_U", "hermitian", "rectangular", "row_slice", "multi_batch"])
+def test_dense_expansion_leaf_by_leaf(built, oracle, monkeypatch, case):
+    """to_dense / to_dense_in_user_numbering / to_dense_device (src/htool/hmatrix/hmatrix.hpp:140-151) read every leaf once and write
+    its 64 x 64 tiles (device_expand.inc): against products with unit vectors (the same panels through the product kernels,
+    <= 1e-13 relative), the exact kernel matrix (< eps), in both numberings; one-triangle storage (the mirrored tiles, conjugated
+    for 'H'), rectangular operators, the row slice of a partition member, several pack batches."""
+    import Htool
+    from tests.helpers import ComplexNumpyGenerator, NumpyGenerator, cluster_of
+
+    O = oracle
+    rng = np.random.RandomState(11)
+    eps = 1e-6
+    cplx = case in ("complex", "hermitian")
+    sub = None
+    if case == "rectangular":
+        T, S = rng.random_sample((3, 1500)), rng.random_sample((3, 700)) + np.array([[0.3], [0.0], [0.0]])
+        tcl, scl = cluster_of(T, 20), cluster_of(S, 20)
+        H = Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N").build(NumpyGenerator(T, S), tcl, scl)
+        A = O.kernel_block(O.K_INV_DELTA, T, S, 0.1)
+    elif case == "hermitian":
+        n = 2000
+        T = S = O.points_in_sphere(n)
+        theta = 3.0 * T[0]
+
+        class HermitianGenerator(Htool.ComplexVirtualGenerator):
+            def build_submatrix(self, J, K, mat):
+                mat[:, :] = np.exp(1j * (theta[J][:, None] - theta[K][None, :])) * O.kernel_block(0, T[:, J], T[:, K], 0.1)
+
+        A = np.exp(1j * (theta[:, None] - theta[None, :])) * O.kernel_block(0, T, T, 0.1)
+        b = Htool.ComplexHMatrixTreeBuilder(eps, 10.0, "H", "U")
+        b.set_symmetric_storage(True)
+        tcl = scl = cluster_of(T, 25)
+        gen = HermitianGenerator()
+        H = b.build(gen, tcl, scl)
+        assert H.is_one_triangle()
+    elif case == "complex":
+        T, S = rng.random_sample((3, 900)), rng.random_sample((3, 1300))
+        tcl, scl = cluster_of(T, 20), cluster_of(S, 20)
+        H = Htool.ComplexHMatrixTreeBuilder(eps, 10.0, "N", "N").build(ComplexNumpyGenerator(T, S, 5.0), tcl, scl)
+        A = O.kernel_block(O.K_HELMHOLTZ, T, S, 5.0)
+    elif case == "row_slice":
+        T = S = O.points_in_sphere(4000)
+        cb = Htool.ClusterTreeBuilder()
+        cb.set_maximal_leaf_size(40)
+        tcl = scl = cb.create_cluster_tree(T, 2, size_of_partition=3)
+        H = Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N").build(Htool.NativeGenerator("laplace", T, S), tcl, scl, 1)
+        sub = tcl.get_cluster_on_partition(1)
+        A = O.kernel_block(O.K_LAPLACE, T, S, 0.0)
+    else:
+        n = 12000 if case == "multi_batch" else 5000
+        if case == "multi_batch":
+            monkeypatch.setenv("HTOOL_BUILD_ARENA_MB", "20")
+        T = S = O.points_in_sphere(n)
+        tcl = scl = cluster_of(T, 50)
+        sym = ("S", case[-1]) if case.startswith("one_triangle") else ("N", "N")
+        H = Htool.HMatrixTreeBuilder(eps, 10.0, *sym).build(Htool.NativeGenerator("laplace", T, S), tcl, scl)
+        assert H.is_one_triangle() == case.startswith("one_triangle")
+        A = O.kernel_block(O.K_LAPLACE, T, S, 0.0)
+    nt, ns = H.shape
+    if sub is not None:  # the block's rows in cluster order, all columns in user numbering... of the local block: both slices in cluster order
+        perm = np.asarray(tcl.get_permutation())
+        rows = perm[sub.get_offset(): sub.get_offset() + sub.get_size()]
+        Dl = np.asarray(H.to_dense())
+        assert Dl.shape == (sub.get_size(), ns)
+        assert np.linalg.norm(Dl - A[np.ix_(rows, perm)]) / np.linalg.norm(A[rows]) < 10 * eps
+        cols = rng.choice(ns, 24, replace=False)
+        E = np.zeros((ns, 24), order="F")
+        E[cols, np.arange(24)] = 1.0
+        Y = H @ E   # x in user numbering, the local rows in cluster order
+        inv = np.empty(ns, dtype=np.int64)
+        inv[perm] = np.arange(ns)
+        assert np.linalg.norm(Dl[:, inv[cols]] - Y) <= 1e-13 * np.linalg.norm(Y)
+        return
+    Du = np.asarray(H.to_dense_in_user_numbering())
+    Dc = np.asarray(H.to_dense())
+    assert Du.shape == (nt, ns) == Dc.shape
+    assert np.linalg.norm(Du - A) / np.linalg.norm(A) < 10 * eps
+    pt, ps = np.asarray(tcl.get_permutation()), np.asarray(scl.get_permutation())
+    assert np.array_equal(Dc, Du[np.ix_(pt, ps)])
+    cols = rng.choice(ns, 24, replace=False)
+    E = np.zeros((ns, 24), dtype=Du.dtype, order="F")
+    E[cols, np.arange(24)] = 1.0
+    Y = H @ E
+    assert np.linalg.norm(Du[:, cols] - Y) <= 1e-13 * np.linalg.norm(Y)
+    if case.startswith("one_triangle"):
+        assert np.abs(Du - Du.T).max() <= 1e-13 * np.abs(Du).max()
+    if case == "hermitian":
+        assert np.abs(Du - Du.conj().T).max() <= 1e-13 * np.abs(Du).max()
