@@ -159,7 +159,8 @@ bool device_to_dense_host(const HMatrix &H, void *out) {
 }
 
 struct DeviceDenseFactor {
-    int kind = 0, n = 0, device = 0;
+    int kind = 0, n = 0, device = 0; // kind: what the matrix holds (1 LU, 2 Cholesky)
+    int asked = 0;                   // what the caller asked for (an LU request for a symmetric operator may hold a Cholesky factor)
     bool is_complex = false;
     char uplo = 'L';
     void *a = nullptr;
@@ -172,7 +173,7 @@ struct DeviceDenseFactor {
     }
 };
 void device_dense_factor_free(DeviceDenseFactor *f) { delete f; }
-int device_dense_factor_kind(const DeviceDenseFactor *f) { return f ? f->kind : 0; }
+int device_dense_factor_kind(const DeviceDenseFactor *f) { return f ? f->asked : 0; }
 
 // kind 1 = LU with partial pivoting, 2 = Cholesky (real, uplo triangle of the dense copy); shift is added to the diagonal first
 DeviceDenseFactor *device_dense_factor(const HMatrix &H, int kind, char uplo, double shift) {
@@ -184,7 +185,7 @@ DeviceDenseFactor *device_dense_factor(const HMatrix &H, int kind, char uplo, do
     const int n = D->row_size;
     const size_t es = H.is_complex ? 16 : 8;
     std::unique_ptr<DeviceDenseFactor> f(new DeviceDenseFactor);
-    f->kind = kind; f->n = n; f->is_complex = H.is_complex; f->uplo = uplo; f->device = D->device;
+    f->kind = kind; f->asked = kind; f->n = n; f->is_complex = H.is_complex; f->uplo = uplo; f->device = D->device;
     HIP_OK(hipSetDevice(D->device));
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
@@ -196,26 +197,49 @@ DeviceDenseFactor *device_dense_factor(const HMatrix &H, int kind, char uplo, do
     HIP_OK(hipMalloc(&f->a, std::max<size_t>((size_t)n * n * es, 1)));
     HIP_OK(hipMalloc((void **)&f->ipiv, sizeof(int64_t) * std::max(n, 1)));
     HIP_OK(hipMalloc((void **)&f->info, sizeof(int64_t)));
-    const double t0 = wall_seconds();
-    device_to_dense_device(H, f->a, n, D->stream);
-    const double t1 = wall_seconds();
-    log_message(LOG_DEBUG, strprintf("dense copy of the %d x %d operator on the device: %.3f s", n, n, t1 - t0));
-    if (shift != 0.0 && n > 0) {
-        if (H.is_complex) hipLaunchKernelGGL(add_to_diagonal_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, D->stream, (double2 *)f->a, (long long)n, n, shift);
-        else hipLaunchKernelGGL(add_to_diagonal_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, D->stream, (double *)f->a, (long long)n, n, shift);
-    }
     HM_CHECK(g_solver.create_handle(&f->handle) == 0, "rocblas_create_handle failed");
     HM_CHECK(g_solver.set_stream(f->handle, D->stream) == 0, "rocblas_set_stream failed");
-    rb_status rs;
-    if (kind == 1) rs = H.is_complex ? g_solver.zgetrf(f->handle, n, n, (rb_z *)f->a, n, f->ipiv, f->info) : g_solver.dgetrf(f->handle, n, n, (double *)f->a, n, f->ipiv, f->info);
-    else rs = g_solver.dpotrf(f->handle, uplo == 'U' ? RB_UPPER : RB_LOWER, n, (double *)f->a, n, f->info);
-    HM_CHECK(rs == 0, strprintf("the dense solver library reported status %d", rs));
-    int64_t info = 0;
-    HIP_OK(hipMemcpyAsync(&info, f->info, sizeof(int64_t), hipMemcpyDeviceToHost, D->stream));
-    HIP_OK(hipStreamSynchronize(D->stream));
+    double t_expand = 0;
+    auto expand = [&]() {
+        const double t0 = wall_seconds();
+        device_to_dense_device(H, f->a, n, D->stream);
+        if (shift != 0.0 && n > 0) {
+            if (H.is_complex) hipLaunchKernelGGL(add_to_diagonal_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, D->stream, (double2 *)f->a, (long long)n, n, shift);
+            else hipLaunchKernelGGL(add_to_diagonal_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, D->stream, (double *)f->a, (long long)n, n, shift);
+        }
+        t_expand += wall_seconds() - t0;
+    };
+    auto run = [&](int what) { // the factorisation in place; returns the library's info (0: done)
+        rb_status rs;
+        if (what == 1) rs = H.is_complex ? g_solver.zgetrf(f->handle, n, n, (rb_z *)f->a, n, f->ipiv, f->info) : g_solver.dgetrf(f->handle, n, n, (double *)f->a, n, f->ipiv, f->info);
+        else rs = g_solver.dpotrf(f->handle, f->uplo == 'U' ? RB_UPPER : RB_LOWER, n, (double *)f->a, n, f->info);
+        HM_CHECK(rs == 0, strprintf("the dense solver library reported status %d", rs));
+        int64_t info = 0;
+        HIP_OK(hipMemcpyAsync(&info, f->info, sizeof(int64_t), hipMemcpyDeviceToHost, D->stream));
+        HIP_OK(hipStreamSynchronize(D->stream));
+        return info;
+    };
+    const double t_begin = wall_seconds();
+    expand();
+    log_message(LOG_DEBUG, strprintf("dense copy of the %d x %d operator on the device: %.3f s", n, n, t_expand));
+    int64_t info = -1;
+    // an LU of a real SYMMETRIC operator ('S': the block of a symmetric operator a DDM preconditioner inverts, use_ddm_solver.py:42):
+    // Cholesky costs half the arithmetic; if the matrix turns out not to be positive definite the copy is written again (cheap:
+    // leaf by leaf) and factorised with pivoting after all.  HTOOL_DENSE_LU_CHOLESKY=0: always with pivoting.
+    static const bool chol_off = getenv("HTOOL_DENSE_LU_CHOLESKY") && std::string(getenv("HTOOL_DENSE_LU_CHOLESKY")) == "0";
+    if (kind == 1 && !H.is_complex && H.params.symmetry == 'S' && !chol_off && n > 0) {
+        f->uplo = 'L';
+        info = run(2);
+        if (info == 0) f->kind = 2;
+        else {
+            log_message(LOG_DEBUG, strprintf("lu_factorization of a symmetric operator: not positive definite (leading minor %lld), factorising with pivoting", (long long)info));
+            expand();
+        }
+    }
+    if (info != 0) info = run(f->kind);
     HM_CHECK(info == 0, kind == 1 ? "lu_factorization: singular matrix" : "cholesky_factorization: matrix is not positive definite");
     log_message(LOG_INFO, strprintf("dense %s of the %d x %d operator on the device: expansion %.3f s, factorisation %.3f s (dense fallback: hierarchical LU is not part of this engine)",
-                                    kind == 1 ? "LU" : "Cholesky", n, n, t1 - t0, wall_seconds() - t1));
+                                    f->kind == 1 ? "LU" : (kind == 1 ? "LU by Cholesky (symmetric positive definite)" : "Cholesky"), n, n, t_expand, wall_seconds() - t_begin - t_expand));
     return f.release();
 }
 

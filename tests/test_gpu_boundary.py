@@ -436,3 +436,34 @@ def test_dense_expansion_leaf_by_leaf(built, oracle, monkeypatch, case):
         assert np.abs(Du - Du.T).max() <= 1e-13 * np.abs(Du).max()
     if case == "hermitian":
         assert np.abs(Du - Du.conj().T).max() <= 1e-13 * np.abs(Du).max()
+
+
+@pytest.mark.parametrize("kernel,definite", [("inv_delta", True), ("laplace", False)])
+def test_lu_of_a_symmetric_operator_tries_cholesky_first(built, oracle, monkeypatch, caplog, kernel, definite):
+    """lu_factorization of a real operator with symmetry 'S' on the device: Cholesky first (half the arithmetic); an operator that
+    is not positive definite -- the Laplace kernel matrix has a zero diagonal -- is expanded again and factorised with pivoting.
+    lu_solve gives the solution either way."""
+    import logging
+
+    import Htool
+    from tests.helpers import cluster_of
+
+    O = oracle
+    monkeypatch.setenv("HTOOL_DENSE_FACTOR", "device")
+    n = 2500
+    np.random.seed(4)
+    pts = O.points_in_sphere(n)
+    cl = cluster_of(pts, 32)
+    kind, p0 = (0, 0.1) if kernel == "inv_delta" else (1, 0.0)
+    H = Htool.HMatrixTreeBuilder(1e-9, 10.0, "S", "L").build(Htool.NativeGenerator(kernel, pts, pts, p0), cl, cl)
+    A = O.kernel_block(kind, pts, pts, p0)
+    X = np.random.rand(n, 2)
+    with caplog.at_level(logging.DEBUG, logger="Htool"):
+        H.lu_factorization()
+    text = " ".join(r.getMessage() for r in caplog.records)
+    assert ("LU by Cholesky" in text) == definite
+    assert ("not positive definite" in text) == (not definite)
+    Y = H.lu_solve("N", np.asfortranarray(A @ X))
+    assert np.linalg.norm(Y - X) / np.linalg.norm(X) < 1e-4
+    Yt = H.lu_solve("T", np.asfortranarray(A @ X))
+    assert np.linalg.norm(Yt - X) / np.linalg.norm(X) < 1e-4

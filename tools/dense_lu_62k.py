@@ -10,7 +10,8 @@ pts = points_in_sphere(n, seed=0)
 b = Htool.ClusterTreeBuilder(); b.set_maximal_leaf_size(100)
 cl = b.create_cluster_tree(pts, 2, size_of_partition=world)
 gen = Htool.NativeGenerator("inv_delta", pts, pts, 0.1)
-Hb = Htool.HMatrixTreeBuilder(1e-6, 10.0, "N", "N").build_local(gen, cl, cl, p, p)
+sym = sys.argv[2] if len(sys.argv) > 2 else "N"   # "S": the block of a symmetric operator (lu_factorization then tries Cholesky first)
+Hb = Htool.HMatrixTreeBuilder(1e-6, 10.0, sym, "L" if sym == "S" else "N").build_local(gen, cl, cl, p, p)
 size = Hb.shape[0]
 print("block", Hb.shape, flush=True)
 x_ref = np.random.RandomState(1).rand(size)
