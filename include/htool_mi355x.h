@@ -189,15 +189,17 @@ int htool_hmatrix_matmat_device(const htool_hmatrix *h, const void *X_dev, int64
  * one entry per row of this H-matrix: its local row slice when cluster-numbered), the "out" side the source side */
 int htool_hmatrix_matmat_device_trans(const htool_hmatrix *h, char trans, const void *X_dev, int64_t ldx, void *Y_dev, int64_t ldy, int mu, int numbering, void *stream);
 
-/* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46) */
+/* dense expansion, column-major nb_rows x nb_cols (hmatrix.hpp:32-46): written leaf by leaf on the device (every panel read once),
+ * downloaded, permuted to the caller's numbering */
 int htool_hmatrix_to_dense(const htool_hmatrix *h, void *out, int user_numbering);
 
 /* H-LU / H-Cholesky (hmatrix.hpp:58-94): hierarchical factorisations are NOT part of this engine.  So that code written for the
  * reference still runs -- in particular the one-level DDM preconditioner, which factorises the rank's diagonal block
  * (example/use_ddm_solver.py:48-63) -- these entries factorise a DENSE copy of the operator:
- *   - whole-cluster operators of at most 20000 unknowns: dense(H) by GPU products, factorised on the host (partial pivoting);
- *   - larger operators and partition-built blocks (block_diagonal_hmatrix): dense(H) expanded ON THE DEVICE (sweeps of 16
- *     unit vectors on the matrix cores) and factorised there by the dense solver library (rocSOLVER, loaded at run time);
+ *   - whole-cluster operators of at most 20000 unknowns: dense(H) downloaded, factorised on the host (partial pivoting);
+ *   - larger operators and partition-built blocks (block_diagonal_hmatrix): dense(H) written ON THE DEVICE, leaf by leaf, and
+ *     factorised there by the dense solver library (rocSOLVER, loaded at run time); an LU request for a real operator with
+ *     symmetry 'S' tries Cholesky first and falls back to pivoting if the matrix is not positive definite;
  *     the limit is the memory of the dense copy (62500 unknowns = 31 GB).  HTOOL_DENSE_FACTOR=device / host forces one path.
  * A WARNING is logged either way.  kind: 1 = LU, 2 = Cholesky; B is n x mu column-major in user numbering (cluster order of
  * the block for partition-built operators), overwritten by the solution. */
