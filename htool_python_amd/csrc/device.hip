@@ -305,6 +305,29 @@ static void ensure_w16(DeviceHMatrix *D) {
             HIP_OK(dev_malloc(&D->xt16, (size_t)std::max<long long>(D->xt_stride, 1) * 16 * D->esize));
             HIP_OK(hipMemset(D->xt16, 0, (size_t)std::max<long long>(D->xt_stride, 1) * 16 * D->esize));
         }
+        // the finishing pass is a gather over the destinations: the tile of every position of the accumulator, and the inverse of
+        // the permutation the results leave by (target side for one-triangle storage, source side for the transposed product)
+        if (D->n_zd_tiles) {
+            std::vector<int> rows(2 * (size_t)D->n_zd_tiles);
+            HIP_OK(hipMemcpy(rows.data(), D->zd_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost));
+            int npos = 0;
+            for (int t = 0; t < D->n_zd_tiles; t++) npos = std::max(npos, rows[2 * t] + rows[2 * t + 1]);
+            std::vector<int> tile_of((size_t)npos, 0), perm((size_t)npos), iperm((size_t)npos, 0);
+            for (int t = 0; t < D->n_zd_tiles; t++)
+                for (int i = 0; i < rows[2 * t + 1]; i++) tile_of[(size_t)rows[2 * t] + i] = t;
+            HIP_OK(hipMemcpy(perm.data(), D->one_triangle ? D->perm_t : D->perm_s, perm.size() * sizeof(int), hipMemcpyDeviceToHost));
+            bool is_perm = true;
+            std::vector<char> seen((size_t)npos, 0);
+            for (int p = 0; p < npos; p++) {
+                if (perm[p] < 0 || perm[p] >= npos || seen[(size_t)perm[p]]) { is_perm = false; break; }
+                seen[(size_t)perm[p]] = 1;
+                iperm[(size_t)perm[p]] = p;
+            }
+            HM_CHECK(is_perm, "internal error: the output numbering of the fused sweep is not a permutation of its positions");
+            D->fin_tile_of = upload(tile_of);
+            D->fin_iperm = upload(iperm);
+            D->fin_npos = npos;
+        }
     }
     D->W16 = w;
 }
@@ -351,8 +374,8 @@ static void launch_sweep16_sym(DeviceHMatrix *D, const T *x, long long x_stride,
                                   (const double *)W16, cj);
     if (D->n_redz16) hipLaunchKernelGGL(reduce_partials16_kernel<T>, dim3(D->n_redz16), dim3(256), 0, st, (const Reduce16 *)D->redz16, W16);
     if (D->nAT) hipLaunchKernelGGL(tile_gemm_tall16_transposed<CPLX>, dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const double *)W16, (double *)D->ycl16, cj);
-    if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym16_kernel<T>, dim3(D->n_zd_tiles), dim3(256), 0, st, (const T *)D->ycl16, (const T *)W16, D->zd_ptr, D->zd_woff, D->zd_rows,
-                                          out_user ? D->perm_t : (const int *)nullptr, y, nr, y_stride);
+    if (D->fin_npos) hipLaunchKernelGGL(finish_sym16_kernel<T>, dim3((unsigned)((D->fin_npos + 63) / 64)), dim3(256), 0, st, (const T *)D->ycl16, (const T *)W16, D->zd_ptr, D->zd_woff, D->zd_rows,
+                                        D->fin_tile_of, out_user ? D->fin_iperm : (const int *)nullptr, y, D->fin_npos, nr, y_stride);
     if (timing) HIP_OK(hipEventRecord(ev[4], st));
     HIP_OK(hipGetLastError());
     if (timing) D->nprod++;
@@ -371,8 +394,8 @@ static void launch_sweep16_T(DeviceHMatrix *D, const T *x, long long x_stride, T
     if (D->n_redz16) hipLaunchKernelGGL(reduce_partials16_kernel<T>, dim3(D->n_redz16), dim3(256), 0, st, (const Reduce16 *)D->redz16, W16);
     HIP_OK(hipMemsetAsync(D->ycl16, 0, (size_t)std::max<long long>(D->ycl_stride, 1) * 16 * sizeof(T), st));
     if (D->nAT) hipLaunchKernelGGL(tile_gemm_tall16_transposed<CPLX>, dim3(D->nAT), dim3(256), 0, st, D->tilesAT, D->segs, (const double *)W16, (double *)D->ycl16, cj);
-    if (D->n_zd_tiles) hipLaunchKernelGGL(finish_sym16_kernel<T>, dim3(D->n_zd_tiles), dim3(256), 0, st, (const T *)D->ycl16, (const T *)W16, D->zd_ptr, D->zd_woff, D->zd_rows,
-                                          out_user ? D->perm_s : (const int *)nullptr, y, nr, y_stride);
+    if (D->fin_npos) hipLaunchKernelGGL(finish_sym16_kernel<T>, dim3((unsigned)((D->fin_npos + 63) / 64)), dim3(256), 0, st, (const T *)D->ycl16, (const T *)W16, D->zd_ptr, D->zd_woff, D->zd_rows,
+                                        D->fin_tile_of, out_user ? D->fin_iperm : (const int *)nullptr, y, D->fin_npos, nr, y_stride);
     HIP_OK(hipGetLastError());
 }
 
@@ -658,7 +681,7 @@ void device_free(DeviceHMatrix *D) {
         if (B.zidxB) (void)hipFree(B.zidxB);
         if (B.tidxA) (void)hipFree(B.tidxA);
     }
-    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16, D->xt, D->redz16, D->ycl16, D->xt16})
+    for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16, D->xt, D->redz16, D->ycl16, D->xt16, (void *)D->fin_tile_of, (void *)D->fin_iperm})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
                     (void *)D->perm_t, (void *)D->iota, (void *)D->ones_idx, D->W, D->x_tmp, D->y_tmp, (void *)D->tcoord, (void *)D->scoord, (void *)D->tilesB_split, D->ypart})

@@ -124,6 +124,8 @@ struct DeviceHMatrix {
     void *redz16 = nullptr;
     int n_redz16 = 0;
     void *ycl16 = nullptr, *xt16 = nullptr;
+    int *fin_tile_of = nullptr, *fin_iperm = nullptr; // finishing pass as a gather: tile of every position, inverse of the output permutation
+    int fin_npos = 0;
     void *W = nullptr;
     long long W_elems = 0;   // elements of ONE coefficient workspace; W holds rhs_cap of them back to back
     int rhs_cap = 0;
