@@ -21,6 +21,18 @@ std::string &htool_error_slot() { return g_err; }
 
 static inline const ClusterHandle *CH(const htool_cluster *c) { return reinterpret_cast<const ClusterHandle *>(c); }
 
+// Where the cluster tree is built.  Both builders give the same tree bit for bit (tests/test_gpu_cluster_tree.py), so this is a
+// question of time only: the GPU for everything but small clouds (its fixed cost is some thirty launches per level),
+// HTOOL_CLUSTER_TREE=host|device overrides, HTOOL_CLUSTER_DEVICE_MIN moves the threshold.
+static bool cluster_tree_on_device(int n_points, int max_leaf) {
+    const char *e = getenv("HTOOL_CLUSTER_TREE");
+    if (e && !std::strcmp(e, "host")) return false;
+    if (max_leaf < 1 || device_count() == 0) return false;
+    if (e && !std::strcmp(e, "device")) return true;
+    const char *m = getenv("HTOOL_CLUSTER_DEVICE_MIN");
+    return n_points >= (m ? atoi(m) : 32768);
+}
+
 extern "C" {
 
 const char *htool_last_error(void) { return g_err.c_str(); }
@@ -58,7 +70,7 @@ int htool_cluster_create(const double *coordinates, int n_points, int dim, const
                          int size_of_partition, const int *partition, int partition_is_local, int maximal_leaf_size, int strategy, htool_cluster **out) {
     API_BEGIN
     ClusterBuildArgs a{coordinates, n_points, dim, radii, weights, number_of_children, size_of_partition, partition, partition_is_local != 0, maximal_leaf_size, strategy};
-    ClusterTree *T = build_cluster_tree(a);
+    ClusterTree *T = cluster_tree_on_device(n_points, maximal_leaf_size) ? build_cluster_tree_device(a) : build_cluster_tree(a);
     *out = reinterpret_cast<htool_cluster *>(T->handle(0));
     API_END
 }

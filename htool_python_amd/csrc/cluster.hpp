@@ -44,6 +44,9 @@ struct ClusterBuildArgs {
 };
 
 ClusterTree *build_cluster_tree(const ClusterBuildArgs &a);
+// the same tree, bit for bit, built on the GPU (cluster_device.hip); needs a HIP device and maximal_leaf_size >= 1
+ClusterTree *build_cluster_tree_device(const ClusterBuildArgs &a);
+size_t cluster_device_release_workspace();
 ClusterTree *cluster_tree_from_tables(int n_points, int dim, int max_leaf, int n_children, const int *perm, int n_nodes, const int *ints7, const double *doubles4);
 
 } // namespace hm

@@ -53,6 +53,8 @@ void device_select(int dev) {
     g_device = dev;
 }
 
+int device_current() { return g_device; }
+
 std::string device_name() {
     if (device_count() == 0) return "";
     hipDeviceProp_t p;
