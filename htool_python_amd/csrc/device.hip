@@ -219,6 +219,14 @@ static void drop_product_graph(DeviceHMatrix *D) {
     D->graph = ProductGraph();
 }
 
+// the first segment of every tile of a reduction table points into the coefficient workspace: move it to the new workspace
+__global__ void relocate_segments_kernel(const GTile *tiles, int n, GSeg *segs, const char *old_base, const char *new_base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GSeg &sg = segs[tiles[i].seg_begin];
+    sg.panel = new_base + ((const char *)sg.panel - old_base);
+}
+
 // make room for nr coefficient workspaces (and partial-y slabs); W[r][n_source] = 1 for every r
 template <typename T>
 static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
@@ -230,28 +238,17 @@ static void ensure_rhs_capacity(DeviceHMatrix *D, int nr) {
     T one;
     std::memset(&one, 0, sizeof(T));
     *(double *)&one = 1.0;
-    for (int r = 0; r < nr; r++) HIP_OK(hipMemcpy((char *)nW + ((size_t)r * D->W_elems + D->n_source) * sizeof(T), &one, sizeof(T), hipMemcpyHostToDevice));
-    // A2 segments point into W: relocate them
-    if (D->W && D->nA2) {
-        std::vector<GTile> t((size_t)D->nA2);
-        HIP_OK(hipMemcpy(t.data(), D->tilesA2, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
-        for (auto &x : t) {
-            GSeg sg;
-            HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
-            sg.panel = (const char *)nW + ((const char *)sg.panel - (const char *)D->W);
-            HIP_OK(hipMemcpy(D->segs + x.seg_begin, &sg, sizeof(GSeg), hipMemcpyHostToDevice));
-        }
+    {
+        std::vector<T> ones((size_t)nr, one);
+        HIP_OK(hipMemcpy2D((char *)nW + (size_t)D->n_source * sizeof(T), (size_t)D->W_elems * sizeof(T), ones.data(), sizeof(T), sizeof(T), (size_t)nr, hipMemcpyHostToDevice));
     }
-    if (D->W && D->nZ) { // so do the panels of the transposed partial sums (one-triangle storage)
-        std::vector<GTile> t((size_t)D->nZ);
-        HIP_OK(hipMemcpy(t.data(), D->tilesZ, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
-        for (auto &x : t) {
-            GSeg sg;
-            HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
-            sg.panel = (const char *)nW + ((const char *)sg.panel - (const char *)D->W);
-            HIP_OK(hipMemcpy(D->segs + x.seg_begin, &sg, sizeof(GSeg), hipMemcpyHostToDevice));
-        }
-    }
+    // the A2 segments, and the panels of the transposed partial sums (one-triangle storage), point into W: relocate them on the
+    // device, one launch per table (round 3 read and rewrote one 64-byte record per tile with blocking copies: some 30 000 of
+    // them at 1 M points, longer than the build of the operator)
+    if (D->W && D->nA2) hipLaunchKernelGGL(relocate_segments_kernel, dim3((unsigned)((D->nA2 + 255) / 256)), dim3(256), 0, 0, D->tilesA2, D->nA2, D->segs, (const char *)D->W, (const char *)nW);
+    if (D->W && D->nZ) hipLaunchKernelGGL(relocate_segments_kernel, dim3((unsigned)((D->nZ + 255) / 256)), dim3(256), 0, 0, D->tilesZ, D->nZ, D->segs, (const char *)D->W, (const char *)nW);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
     if (D->W) (void)hipFree(D->W);
     D->W = nW;
     if (D->one_triangle || D->transposable) {
@@ -277,9 +274,11 @@ static std::vector<Reduce16> reduce16_items(DeviceHMatrix *D, const GTile *tiles
     if (!n) return items;
     std::vector<GTile> t((size_t)n);
     HIP_OK(hipMemcpy(t.data(), tiles, t.size() * sizeof(GTile), hipMemcpyDeviceToHost));
+    std::vector<GSeg> segs((size_t)D->n_segs); // the whole table in one copy (not one blocking copy per tile)
+    HIP_OK(hipMemcpy(segs.data(), D->segs, segs.size() * sizeof(GSeg), hipMemcpyDeviceToHost));
     for (const GTile &x : t) {
-        GSeg sg;
-        HIP_OK(hipMemcpy(&sg, D->segs + x.seg_begin, sizeof(GSeg), hipMemcpyDeviceToHost));
+        HM_CHECK(x.seg_begin >= 0 && x.seg_begin < (long long)segs.size(), "internal error: reduction tile outside the segment table");
+        const GSeg &sg = segs[(size_t)x.seg_begin];
         Reduce16 r;
         r.w_panel = ((const char *)sg.panel - (const char *)D->W) / (long long)D->esize;
         r.out_base = x.out_begin;
@@ -791,6 +790,7 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
     segs.resize((size_t)nseg_used);
     for (auto &s : segs) { s.panel = reloc(s.panel); s.cidx = (const int *)reloc(s.cidx); s.zidx = (const int *)reloc(s.zidx); s.oidx = (const int *)reloc(s.oidx); }
     D->segs = upload(segs);
+    D->n_segs = (long long)segs.size();
     // (the 16-wide workspace of the matrix-core sweep is created again by the copy's first such product)
     dst.dev = D;
     guard.d = nullptr;

@@ -87,6 +87,7 @@ struct DeviceHMatrix {
     size_t esize = 8;
     std::vector<DevBatch> batches;
     GSeg *segs = nullptr;
+    long long n_segs = 0;
     GTile *tilesB_user = nullptr, *tilesB_cluster = nullptr, *tilesA = nullptr, *tilesA2 = nullptr;
     int nB = 0, nA = 0, nA2 = 0;
     // small operators: every row tile is cut in splitB column slices (more, smaller workgroups); the slices
