@@ -200,8 +200,8 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena) {
     } else {
         for (BlockRec &b : dns) g.fn(g.ctx, b.m, b.n, &Tt.perm[b.t_off], &Ss.perm[b.s_off], &arena[b.tmp_u]);
     }
-    H.blocks = done;
-    H.blocks.insert(H.blocks.end(), dns.begin(), dns.end());
+    H.blocks() = done;
+    H.blocks().insert(H.blocks().end(), dns.begin(), dns.end());
 }
 
 template void host_fill_blocks<double>(const Generator &, HMatrix &, std::vector<double> &);

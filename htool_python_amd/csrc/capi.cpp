@@ -184,8 +184,8 @@ static void fill_from_preset(HMatrix &H, const LeafPreset &ps) {
         return m;
     };
     const auto tn = index_nodes(T), sn = (&T == &S) ? tn : index_nodes(S);
-    H.blocks.clear();
-    H.blocks.reserve((size_t)ps.n_leaves);
+    H.blocks().clear();
+    H.blocks().reserve((size_t)ps.n_leaves);
     for (int64_t i = 0; i < ps.n_leaves; i++) {
         const int *l = ps.leaves5 + 5 * i;
         auto it = tn.find(std::make_pair(l[0], l[1]));
@@ -205,7 +205,7 @@ static void fill_from_preset(HMatrix &H, const LeafPreset &ps) {
             const bool lower = H.params.uplo == 'L';
             HM_CHECK(lower ? b.s_off < b.t_off + b.m : b.t_off < b.s_off + b.n, "one-triangle storage: a leaf lies in the triangle that is not stored");
         }
-        H.blocks.push_back(b);
+        H.blocks().push_back(b);
     }
     // The leaves have to tile the operator: no gaps, no overlaps (a truncated or mismatched file would otherwise give a wrong
     // operator without any error).  Every leaf is a pair of cluster nodes (checked above), so its rows are a union of whole row
@@ -215,7 +215,7 @@ static void fill_from_preset(HMatrix &H, const LeafPreset &ps) {
     struct Piece { int tile, s_off, n; };
     std::vector<Piece> pieces;
     long double area = 0;
-    for (const BlockRec &b : H.blocks) {
+    for (const BlockRec &b : H.blocks()) {
         for (int r = H.rtiles.node_tile_begin[b.t_node]; r < H.rtiles.node_tile_end[b.t_node]; r++) pieces.push_back({r, b.s_off, b.n});
         area += (long double)b.m * b.n * ((H.one_triangle && b.t_off != b.s_off) ? 2 : 1);
     }
@@ -318,7 +318,7 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
         device_build_from_host(H, arena.data(), (int64_t)arena.size());
     }
     H.build_seconds = wall_seconds() - t0;
-    log_message(LOG_INFO, strprintf("H-matrix built: %zu leaves, %.3f s", H.blocks.size(), H.build_seconds));
+    log_message(LOG_INFO, strprintf("H-matrix built: %zu leaves, %.3f s", H.leaf_count(), H.build_seconds));
     return h.release();
 }
 
@@ -356,7 +356,7 @@ int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {
     HMatrix &d = c->H;
     d.tc = s.tc; d.sc = s.sc; d.t_root = s.t_root; d.row_off = s.row_off; d.row_size = s.row_size; d.is_complex = s.is_complex;
     d.s_root = s.s_root; d.col_off = s.col_off; d.col_size = s.col_size; d.local_numbering = s.local_numbering; d.one_triangle = s.one_triangle;
-    d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.ctile_group = s.ctile_group; d.blocks = s.blocks; d.r_elems = s.r_elems;
+    d.params = s.params; d.tile_max = s.tile_max; d.rtiles = s.rtiles; d.ctiles = s.ctiles; d.ctile_group = s.ctile_group; d.blocks() = s.blocks(); d.r_elems = s.r_elems;
     d.build_seconds = s.build_seconds; d.n_batches = s.n_batches; d.transposable = s.transposable;
     c->tch = h->tch; c->sch = h->sch;
     device_clone(s, d);
@@ -730,10 +730,10 @@ htool_hmatrix::~htool_hmatrix() {
     device_dense_factor_free(dfactor);
 }
 extern "C" {
-int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.blocks.size(); }
+int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.leaf_count(); }
 void htool_hmatrix_leaves(const htool_hmatrix *h, int *out5) {
-    for (size_t i = 0; i < h->H.blocks.size(); i++) {
-        const BlockRec &b = h->H.blocks[i];
+    for (size_t i = 0; i < h->H.blocks().size(); i++) {
+        const BlockRec &b = h->H.blocks()[i];
         int *p = out5 + 5 * i;
         p[0] = b.t_off; p[1] = b.m; p[2] = b.s_off; p[3] = b.n; p[4] = b.rank;
     }
@@ -754,7 +754,7 @@ int htool_hmatrix_leaf_panels_bulk(const htool_hmatrix *h, int64_t n, const int6
 void htool_hmatrix_stats(const htool_hmatrix *h, int64_t *out8) {
     const HMatrix &H = h->H;
     int64_t dense = 0, lr = 0, nd = 0, nl = 0, sr = 0, maxr = 0;
-    for (const BlockRec &b : H.blocks) {
+    for (const BlockRec &b : H.blocks()) {
         if (b.rank < 0) { dense += (int64_t)b.m * b.n; nd++; }
         else { lr += (int64_t)b.rank * (b.m + b.n); nl++; sr += b.rank; maxr = std::max<int64_t>(maxr, b.rank); }
     }
@@ -783,7 +783,7 @@ int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap) {
         htool_hmatrix_stats(h, st);
         int64_t dmin = -1, dmax = 0, lmin = -1, lmax = 0, rmin = -1;
         double rmean = 0;
-        for (const BlockRec &b : H.blocks) {
+        for (const BlockRec &b : H.blocks()) {
             int64_t sz = (int64_t)b.m * b.n;
             if (b.rank < 0) { dmin = dmin < 0 ? sz : std::min(dmin, sz); dmax = std::max(dmax, sz); }
             else { lmin = lmin < 0 ? sz : std::min(lmin, sz); lmax = std::max(lmax, sz); rmin = rmin < 0 ? b.rank : std::min<int64_t>(rmin, b.rank); rmean += b.rank; }

@@ -55,6 +55,48 @@ void device_select(int dev) {
 
 int device_current() { return g_device; }
 
+// the leaf records of a device-resident build come to the host on first use
+void HMatrix::materialise_blocks() const {
+    std::lock_guard<std::mutex> lock(blocks_mu);
+    if (!blocks_lazy) return;
+    DeviceHMatrix *D = dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HIP_OK(hipSetDevice(D->device));
+    size_t total = 0;
+    for (const LeafTable &lt : D->leaf_tables) total += lt.n;
+    blocks_.clear();
+    blocks_.resize(total);
+    size_t base = 0;
+    for (LeafTable &lt : D->leaf_tables) {
+        std::unique_ptr<DevBlock[]> hb(new DevBlock[std::max<size_t>(lt.n, 1)]);
+        std::unique_ptr<int2[]> hn(new int2[std::max<size_t>(lt.n, 1)]);
+        if (lt.n) {
+            HIP_OK(hipMemcpy(hb.get(), lt.blocks, lt.n * sizeof(DevBlock), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(hn.get(), lt.nodes, lt.n * sizeof(int2), hipMemcpyDeviceToHost));
+        }
+        const DevBlock *pb = hb.get();
+        const int2 *pn = hn.get();
+        BlockRec *out = blocks_.data() + base;
+        const int batch = lt.batch;
+        parallel_for((long long)lt.n, [&](long long q) {
+            const DevBlock &d = pb[q];
+            BlockRec b;
+            b.t_node = pn[q].x; b.s_node = pn[q].y;
+            b.t_off = d.t_off; b.m = d.m; b.s_off = d.s_off; b.n = d.n; b.rank = d.rank; b.cap = d.cap;
+            b.batch = d.rank == 0 ? -1 : batch;
+            b.tmp_u = d.tmp_u; b.tmp_v = d.tmp_v; b.ucol = d.ucol; b.vcol = d.vcol; b.tpos = d.tpos; b.v_obase = d.v_obase; b.v_ostride = d.v_ostride;
+            b.status = d.status; b.z_obase = d.z_obase; b.z_ostride = d.z_ostride; b.zfin = d.zfin;
+            out[q] = b;
+        });
+        base += lt.n;
+        (void)hipFree(lt.blocks);
+        (void)hipFree(lt.nodes);
+        lt.blocks = nullptr; lt.nodes = nullptr; lt.n = 0;
+    }
+    D->leaf_tables.clear();
+    blocks_lazy = false;
+}
+
 std::string device_name() {
     if (device_count() == 0) return "";
     hipDeviceProp_t p;
@@ -91,7 +133,7 @@ void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems) 
     HIP_OK(dev_malloc(&d_arena, std::max<int64_t>(arena_elems, 1) * es));
     if (arena_elems) HIP_OK(hipMemcpy(d_arena, arena, arena_elems * es, hipMemcpyHostToDevice));
     std::vector<int64_t> all;
-    for (size_t i = 0; i < H.blocks.size(); i++) if (H.blocks[i].rank != 0) all.push_back((int64_t)i);
+    for (size_t i = 0; i < H.blocks().size(); i++) if (H.blocks()[i].rank != 0) all.push_back((int64_t)i);
     if (H.is_complex) db.pack_batch<double2>(all, d_arena, false);
     else db.pack_batch<double>(all, d_arena, false);
     HIP_OK(hipFree(d_arena));
@@ -450,8 +492,8 @@ void device_make_transposable(HMatrix &H) {
     HIP_OK(hipSetDevice(D->device));
     HIP_OK(hipDeviceSynchronize()); // products in flight (on any stream) still read the tables that are replaced below
     std::vector<std::vector<int64_t>> per_batch(D->batches.size());
-    for (size_t i = 0; i < H.blocks.size(); i++) {
-        const BlockRec &b = H.blocks[i];
+    for (size_t i = 0; i < H.blocks().size(); i++) {
+        const BlockRec &b = H.blocks()[i];
         if (b.rank == 0) continue;
         HM_CHECK(b.batch >= 0 && b.batch < (int)per_batch.size(), "internal error: leaf without a batch");
         per_batch[b.batch].push_back((int64_t)i);
@@ -682,6 +724,10 @@ void device_free(DeviceHMatrix *D) {
         if (B.zidxB) (void)hipFree(B.zidxB);
         if (B.tidxA) (void)hipFree(B.tidxA);
     }
+    for (LeafTable &lt : D->leaf_tables) {
+        if (lt.blocks) (void)hipFree(lt.blocks);
+        if (lt.nodes) (void)hipFree(lt.nodes);
+    }
     for (void *p : {(void *)D->tilesAT, (void *)D->tilesZ, (void *)D->zd_ptr, (void *)D->zd_woff, (void *)D->zd_rows, D->ycl, D->W16, D->red16, D->xt, D->redz16, D->ycl16, D->xt16, (void *)D->fin_tile_of, (void *)D->fin_iperm})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)D->segs, (void *)D->tilesB_user, (void *)D->tilesB_cluster, (void *)D->tilesA, (void *)D->tilesA2, (void *)D->perm_s,
@@ -800,9 +846,9 @@ void device_clone(const HMatrix &src, HMatrix &dst) {
 void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *Bout) {
     const DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
-    HM_CHECK(leaf >= 0 && leaf < (int64_t)H.blocks.size(), "leaf index out of range");
+    HM_CHECK(leaf >= 0 && leaf < (int64_t)H.blocks().size(), "leaf index out of range");
     HIP_OK(hipSetDevice(D->device));
-    const BlockRec &b = H.blocks[leaf];
+    const BlockRec &b = H.blocks()[leaf];
     if (b.rank == 0) return;
     const size_t es = D->esize;
     const int vec_rows = H.is_complex ? 1 : 2;

@@ -66,6 +66,15 @@ struct BatchTables {
     int64_t r_end = 0;   // end of the part of the R workspace this batch's layout refers to
 };
 
+struct DevBlock;
+// the leaf records of a batch packed by the device-resident build, kept on the device until the host asks for them
+struct LeafTable {
+    DevBlock *blocks = nullptr;
+    int2 *nodes = nullptr; // (target node, source node) of every leaf
+    size_t n = 0;
+    int batch = -1;
+};
+
 // the launches of one product, captured as a hipGraph the second time the same product (same buffers, same stream) is asked
 // for and replayed from then on: a Krylov loop or a distributed step on fixed buffers then costs one graph launch
 struct ProductGraph {
@@ -86,6 +95,7 @@ struct DeviceHMatrix {
     bool is_complex = false;
     size_t esize = 8;
     std::vector<DevBatch> batches;
+    std::vector<LeafTable> leaf_tables;
     GSeg *segs = nullptr;
     long long n_segs = 0;
     GTile *tilesB_user = nullptr, *tilesB_cluster = nullptr, *tilesA = nullptr, *tilesA2 = nullptr;

@@ -15,6 +15,7 @@
 // [col][ld_q] with ld_q = TM (full chunks) or the remainder rounded up to the vector width.
 #pragma once
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -129,7 +130,15 @@ struct HMatrix {
     int tile_max = 128;
     TileSet rtiles, ctiles;
     std::vector<int> ctile_group;   // group of every source tile (phase A streams a group per workgroup)
-    std::vector<BlockRec> blocks;
+    // The leaf records.  A device-resident build (device_build2.inc) leaves them on the GPU: blocks() fetches them when something
+    // on the host asks (introspection, recompression, save, the tables of the transposed product); leaf_count() never does.
+    mutable std::vector<BlockRec> blocks_;
+    mutable bool blocks_lazy = false;
+    mutable std::mutex blocks_mu;
+    int64_t n_leaves_lazy = 0;
+    std::vector<BlockRec> &blocks() const { if (blocks_lazy) materialise_blocks(); return blocks_; }
+    void materialise_blocks() const; // device.hip
+    size_t leaf_count() const { return blocks_lazy ? (size_t)n_leaves_lazy : blocks_.size(); }
     int64_t r_elems = 0;            // size of region R of W
     double build_seconds = 0;
     int n_batches = 0;
@@ -147,6 +156,16 @@ void split_failed_block(const ClusterTree &T, const ClusterTree &S, const BuildP
 // ---- layout (layout.cpp) ----
 // assigns ucol/vcol/tpos/... of the given blocks (one batch) and fills the BatchLayout.
 void compute_batch_layout(HMatrix &H, const std::vector<int64_t> &batch_blocks, int vec_rows, BatchLayout &L);
+// the part of it that needs per-node sums only (layout.cpp)
+struct NodeLayout {
+    std::vector<int> tbase, sbase;      // first phase-B column / phase-A row of a node's own leaves
+    std::vector<int64_t> tb, pbse;      // per source node: its t vector and its panel of per-group partial sums in R (-1: none), relative to r_start
+    std::vector<int> ldp;
+    std::vector<int64_t> zf, zp;        // per target node (one-triangle storage / transposed products): final slots, per-tile partials (-1: none)
+    std::vector<int> zld;
+    int64_t r_start = 0;                // W index of R[0]
+};
+void compute_node_layout(HMatrix &H, const std::vector<int> &Klr, const std::vector<int> &Kdn, const std::vector<int> &Ks, int vec_rows, BatchLayout &L, NodeLayout &NL);
 
 // ---- host build for callback generators (build_host.cpp) ----
 // runs ACA / the custom compressor / the dense fill on the calling thread; fills a host arena laid out

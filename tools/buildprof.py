@@ -7,11 +7,12 @@ kernel = sys.argv[1] if len(sys.argv) > 1 else "laplace"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 eps = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-3
+leaf = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 pts=points_in_sphere(n, seed=0)
 Htool.set_num_threads(16)
 for rep in range(reps):
     t0=time.time()
-    cb=Htool.ClusterTreeBuilder(); cb.set_maximal_leaf_size(100)
+    cb=Htool.ClusterTreeBuilder(); cb.set_maximal_leaf_size(leaf)
     cl=cb.create_cluster_tree(pts,2,size_of_partition=1)
     t1=time.time()
     if kernel == "helmholtz":
