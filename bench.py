@@ -45,16 +45,16 @@ def pmc_traffic(args, n):
     (profiles/), or None when no pass exists for this workload OR the kernels have changed since the passes were taken
     (the file records the fingerprint of the kernel source it was measured on)."""
     if not (n == 1_000_000 and args.kernel == "laplace" and args.eps == 1e-3 and args.eta == 10.0 and args.leaf == 100 and args.gpus == 1 and args.rhs == 1):
-        return None
-    for name in ("r03_pmc_hbm_traffic_1m_laplace.json",):
+        return None, None
+    for name in ("r04_pmc_hbm_traffic_1m_laplace.json", "r03_pmc_hbm_traffic_1m_laplace.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
         with open(path) as f:
             d = json.load(f)
         if d.get("kernel_source_sha1") == kernel_source_sha1():
-            return d.get("tile_gemv_wide_hbm_bytes_per_launch")
-    return None
+            return d.get("tile_gemv_wide_hbm_bytes_per_launch"), name
+    return None, None
 
 
 def cpu_full_operator(n_points=100_000, eps=1e-4, eta=10.0, leaf=100, budget_s=8.0):
@@ -231,10 +231,15 @@ def main():
     import Htool
     from htool_python_amd.workloads import algorithmic_bytes, points_in_sphere, usable_cpus
 
-    Htool.set_device(local_rank)
-    # host threads for the cluster-tree construction: this rank's share of the CPUs (torchrun exports
-    # OMP_NUM_THREADS=1 for multi-rank launches, and a node-wide default would oversubscribe 8 ranks)
-    Htool.set_num_threads(max(1, min(16, usable_cpus() // world)))
+    Htool.set_device(local_rank)       # (also warms the library up: code objects of all kernels, build streams)
+    warm_up_s = Htool.last_warm_up_seconds()
+    # host threads of this rank (what is left on the host: tiles, per-node layout, table assembly; the cluster tree and the
+    # block tree are built on the GPU): its share of the CPUs, stated in the line (torchrun exports OMP_NUM_THREADS=1 for
+    # multi-rank launches, and a node-wide default would oversubscribe 8 ranks)
+    host_threads = max(1, min(16, usable_cpus() // world))
+    if os.environ.get("HTOOL_BENCH_THREADS"):
+        host_threads = max(1, int(os.environ["HTOOL_BENCH_THREADS"]))
+    Htool.set_num_threads(host_threads)
     is_complex = args.kernel == "helmholtz"
     elem = 16 if is_complex else 8
     dtype = torch.complex128 if is_complex else torch.float64
@@ -256,11 +261,19 @@ def main():
     logging.getLogger("Htool").addHandler(_Keep())
     logging.getLogger("Htool").setLevel(logging.INFO)
     pts = points_in_sphere(n, seed=0)
+    # the cluster tree (built on the GPU, csrc/cluster_device.hip; every rank builds the same tree on its own GPU) -- like the
+    # operator it is built twice: cluster_tree_cold_s is the first tree of the process (workspace allocated), cluster_tree_s the second
     t0 = time.time()
     cb = Htool.ClusterTreeBuilder()
     cb.set_maximal_leaf_size(args.leaf)
     cluster = cb.create_cluster_tree(pts, 2, size_of_partition=world)
-    t_cluster = time.time() - t0
+    t_cluster_cold = time.time() - t0
+    t_cluster = t_cluster_cold
+    if not args.no_warm_build:
+        del cluster
+        t0 = time.time()
+        cluster = cb.create_cluster_tree(pts, 2, size_of_partition=world)
+        t_cluster = time.time() - t0
     param = {"laplace": 0.0, "inv_delta": 0.1, "helmholtz": args.kappa}[args.kernel]
     if is_complex:
         gen = Htool.ComplexNativeGenerator(args.kernel, pts, pts, param)
@@ -470,15 +483,17 @@ def main():
     per_rank = None
     if dist_mode:
         dev = "cuda" if args.backend == "nccl" else "cpu"
-        mine = torch.tensor([tot_bytes, sum(ph) if n_ph else 0.0, exchange_us or 0.0, float(t_build), float(t_build_cold)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([tot_bytes, sum(ph) if n_ph else 0.0, exchange_us or 0.0, float(t_build), float(t_build_cold), float(t_cluster), float(t_cluster_cold), float(host_threads)],
+                            dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"algorithmic_GB": float(v[0]) / 1e9, "product_us": float(v[1]), "exchange_us": float(v[2]), "build_s": float(v[3]), "build_cold_s": float(v[4])} for v in allr]
-        t = torch.tensor([dt, tot_bytes, float(t_build), float(t_build_cold), float(t_cluster)], dtype=torch.float64, device=dev)
+        per_rank = [{"algorithmic_GB": float(v[0]) / 1e9, "product_us": float(v[1]), "exchange_us": float(v[2]), "build_s": float(v[3]), "build_cold_s": float(v[4]),
+                     "cluster_tree_s": float(v[5]), "cluster_tree_cold_s": float(v[6]), "setup_s": float(v[3]) + float(v[5]), "host_threads": int(v[7])} for v in allr]
+        t = torch.tensor([dt, tot_bytes, float(t_build), float(t_build_cold), float(t_cluster), float(t_cluster_cold)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, tot_bytes, t_build, t_build_cold, t_cluster = float(tmax[0]), float(t[1]), float(tmax[2]), float(tmax[3]), float(tmax[4])
+        dt, tot_bytes, t_build, t_build_cold, t_cluster, t_cluster_cold = float(tmax[0]), float(t[1]), float(tmax[2]), float(tmax[3]), float(tmax[4]), float(tmax[5])
     ms_per_step = dt / args.steps * 1e3
     value = tot_bytes / (dt / args.steps) / 1e9
 
@@ -510,8 +525,11 @@ def main():
         "build_s": t_build,
         "build_cold_s": t_build_cold,
         "cluster_tree_s": t_cluster,
+        "cluster_tree_cold_s": t_cluster_cold,
         "setup_s": t_cluster + t_build,
-        "setup_cold_s": t_cluster + t_build_cold,
+        "setup_cold_s": t_cluster_cold + t_build_cold,
+        "warm_up_s": warm_up_s,   # Htool.set_device(): code objects of all kernels loaded, build streams created (before anything is timed)
+        "host_threads": host_threads,
         "build_warmed": not args.no_warm_build,
         "vram_preconditioning": vram_prep,
         "build_breakdown": build_breakdown,
@@ -552,6 +570,7 @@ def main():
         # one-triangle storage: the last event interval holds the fused sweep over the U / dense panels AND the second,
         # transposed, read of the V panels
         bytes_b = ab["phase_b"] + (ab["phase_a"] if fused else 0)
+        traffic, traffic_file = (None, None) if args.symmetric else pmc_traffic(args, n)
         out["roofline"] = {
             "bound": "hbm",
             "kernel": (("tile_gemm_wide16_sym + tile_gemm_tall16_transposed" if args.rhs > 8 else "tile_gemv_wide_sym + tile_gemv_tall_transposed") + " (fused sweep of the stored triangle)") if fused
@@ -560,7 +579,10 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": (bytes_b / t_b / 1e9 / HBM_PEAK_GBPS) if t_b else None,
-            "traffic": None if args.symmetric else pmc_traffic(args, n),
+            # HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes of this command line (rocprof cannot run inside this
+            # process): quoted only while the kernel sources still have the fingerprint the passes were taken on
+            "traffic": traffic,
+            "traffic_source": None if traffic is None else f"profiles/{traffic_file} (FETCH_SIZE x 2 + WRITE_SIZE of separate --pmc passes; kernel sources sha1 {kernel_source_sha1()[:12]})",
             "launch_us": ph[3] if n_ph else None,
             "algorithmic_bytes_per_launch": bytes_b,
             "launches_averaged": n_ph,

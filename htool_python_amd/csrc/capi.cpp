@@ -33,13 +33,17 @@ static bool cluster_tree_on_device(int n_points, int max_leaf) {
     return n_points >= (m ? atoi(m) : 32768);
 }
 
+static double g_warm_up_s = 0.0;
+
 extern "C" {
 
+double htool_last_warm_up_seconds(void) { return g_warm_up_s; }
 const char *htool_last_error(void) { return g_err.c_str(); }
 int htool_device_count(void) { return device_count(); }
 int htool_set_device(int device) {
     API_BEGIN
     device_select(device);
+    if (!(getenv("HTOOL_WARM_UP") && std::string(getenv("HTOOL_WARM_UP")) == "0")) g_warm_up_s = device_warm_up();
     API_END
 }
 const char *htool_device_name(void) {

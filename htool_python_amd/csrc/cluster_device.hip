@@ -797,3 +797,9 @@ ClusterTree *build_cluster_tree_device(const ClusterBuildArgs &a) {
 }
 
 } // namespace hm
+
+// library warm-up (device.hip: device_warm_up): the first launch of a kernel of this translation unit loads its code object
+namespace hm {
+__global__ void warm_kernel_cluster() {}
+void warm_up_cluster() { hipLaunchKernelGGL(warm_kernel_cluster, dim3(1), dim3(64), 0, 0); }
+} // namespace hm

@@ -295,3 +295,9 @@ void device_dense_solve_host(const HMatrix &H, const DeviceDenseFactor *f, char 
     }
     (void)hipFree(d_in); (void)hipFree(d_cl);
 }
+
+// library warm-up (device.hip: device_warm_up): the first launch of a kernel of this translation unit loads its code object
+namespace hm {
+__global__ void warm_kernel_dense() {}
+void warm_up_dense() { hipLaunchKernelGGL(warm_kernel_dense, dim3(1), dim3(64), 0, 0); }
+} // namespace hm

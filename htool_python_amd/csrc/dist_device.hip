@@ -448,3 +448,9 @@ int htool_debug_compact_slices(const void *gathered_dev, void *x_full_dev, const
 }
 
 } // extern "C"
+
+// library warm-up (device.hip: device_warm_up): the first launch of a kernel of this translation unit loads its code object
+namespace hm {
+__global__ void warm_kernel_dist() {}
+void warm_up_dist() { hipLaunchKernelGGL(warm_kernel_dist, dim3(1), dim3(64), 0, 0); }
+} // namespace hm

@@ -177,6 +177,7 @@ void host_fill_blocks(const Generator &g, HMatrix &H, std::vector<T> &arena);
 int device_count();
 void device_select(int dev);
 std::string device_name();
+double device_warm_up(); // loads the code objects, creates the build streams (once per device); returns the seconds it took
 // whole build for a callback generator: upload the host arena, pack, assemble the product tables
 void device_build_from_host(HMatrix &H, const void *arena, int64_t arena_elems);
 // whole build for a native generator: device ACA + dense evaluation + pack

@@ -97,3 +97,9 @@ extern "C" int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu,
     HIP_OK(hipGetLastError());
     API_END
 }
+
+// library warm-up (device.hip: device_warm_up): the first launch of a kernel of this translation unit loads its code object
+namespace hm {
+__global__ void warm_kernel_krylov() {}
+void warm_up_krylov() { hipLaunchKernelGGL(warm_kernel_krylov, dim3(1), dim3(64), 0, 0); }
+} // namespace hm

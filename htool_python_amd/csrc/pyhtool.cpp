@@ -760,6 +760,7 @@ PYBIND11_MODULE(Htool, m) {
     m.def("device_count", &htool_device_count);
     m.def("device_name", []() { return std::string(htool_device_name()); });
     m.def("set_device", [](int d) { check(htool_set_device(d)); });
+    m.def("last_warm_up_seconds", &htool_last_warm_up_seconds, "Seconds the library warm-up of the most recent set_device took (code objects, streams; 0 when the device was warm already)");
     m.def("set_num_threads", &htool_set_num_threads);
     m.def("rccl_unique_id", []() {
         char id[HTOOL_RCCL_UNIQUE_ID_BYTES];

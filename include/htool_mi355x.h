@@ -38,7 +38,10 @@ typedef struct htool_distributed htool_distributed; /* row-partitioned operator 
 /* ---- errors, device, logging -------------------------------------------------------------- */
 const char *htool_last_error(void);
 int htool_device_count(void);          /* number of usable HIP devices (0 on a GPU-less box) */
-int htool_set_device(int device);      /* select the HIP device for objects created afterwards */
+int htool_set_device(int device);      /* select the HIP device for objects created afterwards; the first call for a device also warms
+                                           the library up on it: code objects of all kernels loaded, build streams created (HTOOL_WARM_UP=0:
+                                           not done, the first cluster tree / build of the process then pays for it) */
+double htool_last_warm_up_seconds(void); /* what the warm-up of the most recent htool_set_device took (0: already warm) */
 const char *htool_device_name(void);   /* e.g. "gfx950:..." or "" */
 void htool_set_num_threads(int n);     /* OpenMP threads of the host-side tree construction (0: leave as is) */
 /* Builds and recompressions keep their large temporary device buffers (the ACA arena ...) in a process-wide cache for
