@@ -36,7 +36,10 @@ struct AcaStop {
 #else
         const int before = st;
         st = passed ? (before != 0 ? before + (1 << 20) : (k | (1 << 20))) : 0;
-        if (too_big) { if (before != 0) { k = before & 0xfffff; return 1; } return 2; } // (a test passed earlier: that rank was acceptable)
+        // too many terms to be worth storing.  A pass that was waiting for its confirmation is accepted only when THIS step passed
+        // as well: a confirming step that fails has just shown the earlier rank to be premature (round 3 accepted it anyway and
+        // defeated the safeguard exactly where it matters); the block then goes the way of every block that is not compressible
+        if (too_big) { if (before != 0 && passed) { k = before & 0xfffff; return 1; } return 2; }
         if (passed && (st >> 20) > confirm) { k = st & 0xfffff; return 1; }
         if (no_next_row) { if (st != 0) k = st & 0xfffff; return 1; }
         return 0;

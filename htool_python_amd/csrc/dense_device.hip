@@ -47,11 +47,19 @@ struct SolverLib {
         std::lock_guard<std::mutex> lock(mu); // (factorisations of several handles may start on several host threads)
         if (solver) return true;
         error.clear();
-        blas = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-        if (!blas) blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-        void *s = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-        if (!s) s = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!blas || !s) { error = std::string("the dense solver library could not be loaded (librocblas / librocsolver): ") + (dlerror() ? dlerror() : "?"); return false; }
+        // (dlerror() hands its message out ONCE and clears it: taken right after each failing dlopen, into a string)
+        std::string why;
+        auto open_first = [&](std::initializer_list<const char *> names) -> void * {
+            for (const char *nm : names) {
+                if (void *h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) return h;
+                const char *e = dlerror();
+                why += std::string(why.empty() ? "" : "; ") + (e ? e : "dlopen failed without a message");
+            }
+            return nullptr;
+        };
+        blas = open_first({"librocblas.so.5", "librocblas.so"});
+        void *s = blas ? open_first({"librocsolver.so.0", "librocsolver.so"}) : nullptr;
+        if (!blas || !s) { error = "the dense solver library could not be loaded (librocblas / librocsolver): " + why; return false; }
         auto sym = [&](void *lib, const char *name) { void *p = dlsym(lib, name); if (!p) error = std::string("missing symbol ") + name; return p; };
         *(void **)&create_handle = sym(blas, "rocblas_create_handle");
         *(void **)&destroy_handle = sym(blas, "rocblas_destroy_handle");

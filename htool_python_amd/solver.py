@@ -46,7 +46,7 @@ class DeviceOperator:
         # dist_op: the DistributedOperator this H-matrix belongs to; the exchange + product of apply() is then ONE library call
         # (htool_distributed_matvec_device: RCCL all-gather when the communicator carries a library-owned handle, the same
         # code path staged through the host all-gather of the communicator object when ranks share a GPU)
-        self.dist_op = dist_op if (dist_op is not None and hasattr(dist_op, "exchange_kind") and dist_op.exchange_kind(1) >= 0) else None
+        self.dist_op = dist_op if self._library_exchange_is_the_fast_one(dist_op) else None
         self.H = hmatrix
         self.n = hmatrix.shape[1]
         self.partition = partition or [(0, self.n)]
@@ -55,6 +55,25 @@ class DeviceOperator:
         self.offset, self.size = self.partition[rank]
         self.products = 0
         self._gather = None
+
+    @staticmethod
+    def _library_exchange_is_the_fast_one(dist_op):
+        """The in-library exchange is taken when it runs on device buffers (kinds 0, 1, 2: one rank, or a communicator with a
+        device all-gather hook -- RCCL) or when the process group is gloo anyway (ranks sharing a GPU: the rehearsal path).  Under
+        an nccl process group WITHOUT a library-owned RCCL handle (nobody called comm.use_rccl() before the operator was built)
+        the library would stage every product through the host -- device-to-host copy, stream synchronisation, a Python
+        all-gather callback, host-to-device copy: the SliceGatherer's device all-gather over torch.distributed (also RCCL)
+        stays the exchange then."""
+        if dist_op is None or not hasattr(dist_op, "exchange_kind"):
+            return False
+        kind = dist_op.exchange_kind(1)
+        if kind < 0:
+            return False
+        if kind <= 2 or getattr(dist_op, "has_rccl", False):
+            return True
+        import torch.distributed as tdist
+
+        return not tdist.is_initialized() or tdist.get_backend() == "gloo"
 
     def apply(self, x_local, out=None):
         """x_local: this rank's slice, shape (size,) or (mu, size) (rows may be strided: a slot of a Krylov basis); the result goes

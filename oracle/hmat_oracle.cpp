@@ -374,8 +374,8 @@ static int aca(const Gen &g, int M0, int N0, const int *rows0, const int *cols0,
         const bool streak_before = streak > 0;
         const bool pass = reqrank < 0 && std::sqrt(cn2 * rn2) <= eps * std::sqrt(std::max(frob2, 0.0));
         if (pass) { if (streak == 0) rank_at_first_pass = k; streak++; } else streak = 0;
-        if ((int64_t)k * (M + N) > (int64_t)M * N) { // too many terms to be worth storing -- unless an earlier rank had already passed
-            if (streak_before) { k = rank_at_first_pass; streak = 0; } else failed = true;
+        if ((int64_t)k * (M + N) > (int64_t)M * N) { // too many terms to be worth storing -- unless an earlier rank had passed AND this step confirms it
+            if (streak_before && pass) { k = rank_at_first_pass; streak = 0; } else failed = true;
             break;
         }
         if (pass && streak > confirm) break;
