@@ -798,7 +798,7 @@ int htool_hmatrix_info(const htool_hmatrix *h, int which, char *buf, int cap) {
         o << "Number_of_dense_blocks=" << st[2] << "\nNumber_of_low_rank_blocks=" << st[3] << "\nDense_block_size_max=" << dmax << "\nDense_block_size_min=" << std::max<int64_t>(dmin, 0)
           << "\nLow_rank_block_size_max=" << lmax << "\nLow_rank_block_size_min=" << std::max<int64_t>(lmin, 0) << "\nRank_max=" << st[7] << "\nRank_min=" << std::max<int64_t>(rmin, 0)
           << "\nRank_mean=" << rmean << "\nCompression_ratio=" << (cr > 0 ? 1.0 / cr : 0) << "\nSpace_saving=" << 1 - cr << "\nHBM_bytes=" << st[5]
-          << "\nBuild_seconds=" << H.build_seconds << "\n";
+          << "\nBuild_seconds=" << H.build_seconds << "\nNumber_of_batches=" << H.n_batches << "\n";
     }
     std::string s = o.str();
     if (buf && cap > 0) {

@@ -45,6 +45,8 @@ CASES = [
     dict(n=9000, leaf=30, eps=1e-4, eta=10.0, part=1, nparts=3),     # the rows of one partition member
     dict(n=5000, leaf=20, eps=1e-3, eta=10.0, mins=(3, 2)),          # minimal depths
     dict(n=700, leaf=100, eps=1e-3, eta=10.0),                       # tiny: (nearly) everything dense
+    dict(n=20000, leaf=50, eps=1e-4, eta=10.0, arena_mb=30),         # a forced small arena: several rounds, a batch per round
+    dict(n=12000, leaf=10, eps=1e-3, eta=10.0, arena_mb=8, kind="helmholtz", param=3.0),
 ]
 
 
@@ -52,12 +54,16 @@ CASES = [
 def test_device_resident_build_equals_host_driven_build(built, oracle, monkeypatch, case):
     from htool_python_amd.workloads import points_in_sphere
 
-    c = dict(kind="laplace", sym="N", uplo="N", part=-1, nparts=1, param=0.0, mins=(0, 0))
+    c = dict(kind="laplace", sym="N", uplo="N", part=-1, nparts=1, param=0.0, mins=(0, 0), arena_mb=0)
     c.update(case)
+    if c["arena_mb"]:
+        monkeypatch.setenv("HTOOL_BUILD_ARENA_MB", str(c["arena_mb"]))
     pts = points_in_sphere(c["n"], seed=3)
     kw = dict(kind=c["kind"], sym=c["sym"], uplo=c["uplo"], part=c["part"], nparts=c["nparts"], param=c["param"], mins=c["mins"])
     Hd, ct, cs = _build(monkeypatch, "device", pts, pts, c["leaf"], c["eps"], c["eta"], **kw)
     Hh, _, _ = _build(monkeypatch, "host", pts, pts, c["leaf"], c["eps"], c["eta"], **kw)
+    if c["arena_mb"]:
+        assert int(Hd.get_local_information()["Number_of_batches"]) > 2, "the forced arena was meant to take several rounds"
     assert Hd.is_one_triangle() == Hh.is_one_triangle() == (c["sym"] == "S")
     ld, od = _leaf_table(Hd)
     lh, oh = _leaf_table(Hh)
