@@ -253,13 +253,13 @@ def main():
     class _Keep(logging.Handler):
         def emit(self, record):
             msg = record.getMessage()
-            if "native build timing" in msg:
+            if "native build timing" in msg or "build timeline" in msg:
                 build_log.append(msg)
             elif "H-matrix built" in msg and build_log:  # (the C-ABI call as a whole: tiles, the native build, its clean-up)
                 build_log[-1] += "; " + msg
 
     logging.getLogger("Htool").addHandler(_Keep())
-    logging.getLogger("Htool").setLevel(logging.INFO)
+    logging.getLogger("Htool").setLevel(logging.DEBUG)  # (the build's stage@seconds timeline is a DEBUG line)
     pts = points_in_sphere(n, seed=0)
     # the cluster tree (built on the GPU, csrc/cluster_device.hip; every rank builds the same tree on its own GPU) -- like the
     # operator it is built twice: cluster_tree_cold_s is the first tree of the process (workspace allocated), cluster_tree_s the second
@@ -589,6 +589,12 @@ def main():
             "other_kernels_us": {"x_gather": ph[0], "phase_a_tile_gemv_tall": ph[1], "phase_a2_tile_gemv_tall": ph[2]} if n_ph else None,
             "phase_a_achieved": (ab["phase_a"] / (ph[1] * 1e-6) / 1e9) if n_ph and ph[1] > 0 else None,
         }
+        if args.trans != "N":
+            # the transposed product records no per-phase events: its launches as a whole (x gather -> wide sweep, transposed use
+            # only -> sums of the partials -> V^T pass -> finish), priced with the wall time of a step on the product's stream
+            out["roofline"] = {"bound": "hbm", "kernel": ("tile_gemm_wide16_sym<DIRECT = false> + tile_gemm_tall16_transposed" if args.rhs > 8 else "tile_gemv_wide_sym<DIRECT = false> + tile_gemv_tall_transposed") + " (whole transposed product, all launches)",
+                               "achieved": value, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": value / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                               "launch_us": ms_per_step * 1e3, "algorithmic_bytes_per_launch": tot_bytes, "launches_averaged": args.steps, "other_kernels_us": None, "phase_a_achieved": None}
         out["hmatrix"] = {"n_dense": stats["n_dense"], "n_low_rank": stats["n_low_rank"], "max_rank": stats["max_rank"],
                           "mean_rank": stats["sum_rank"] / max(stats["n_low_rank"], 1), "hbm_resident_GB": stats["hbm_bytes"] / 1e9}
         if world == 1 and not args.no_cpu_baseline and not is_complex:
