@@ -34,7 +34,7 @@ def kernel_source_sha1():
     import hashlib
 
     h = hashlib.sha1()
-    for name in ("product_kernels.inc", "product_mfma.inc", "device_tables.inc", "pack_kernels.inc", "layout.cpp", "blocktree.cpp", "device.hip"):
+    for name in ("product_kernels.inc", "product_mfma.inc", "device_tables.inc", "pack_kernels.inc", "layout.cpp", "blocktree.cpp", "device.hip", "device_build2.inc", "device_scan.inc"):
         with open(os.path.join(ROOT, "htool_python_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

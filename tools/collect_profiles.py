@@ -1,4 +1,4 @@
-"""Copy the evidence of tools/r03_final_profiles.sh + tools/r03_final_benches.sh from gpurun_out/ (scratch) into profiles/ (tracked),
+"""Copy the evidence of tools/r04_final_profiles.sh + tools/r04_final_benches.sh (round 3: r03_*; `python tools/collect_profiles.py r03`) from gpurun_out/ (scratch) into profiles/ (tracked),
 under the round's names, and derive the PMC traffic file bench.py reads.   python tools/collect_profiles.py
 (round 2: tools/final_profiles.sh + tools/final_benches*.sh, prefix r02, directories gpurun_out/final and final2)"""
 import glob
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 F, F2, P = os.path.join(ROOT, "gpurun_out", R + "final"), os.path.join(ROOT, "gpurun_out", R + "final2"), os.path.join(ROOT, "profiles")
 
 
@@ -67,7 +67,7 @@ if os.path.exists(os.path.join(F, "buildprof.log")):
     with open(os.path.join(F, "buildprof.log")) as f, open(os.path.join(P, R + "_build_timeline_1m_laplace.txt"), "w") as g:
         g.write("# python tools/buildprof.py laplace 1000000 4   (DEBUG log of the native build: stage@seconds marks, ACA rounds, pack batches)\n")
         for line in f:
-            if any(k in line for k in ("timeline", "native build timing", "ACA ", "pack batch", "rep ")):
+            if any(k in line for k in ("timeline", "native build", "ACA ", "pack batch", "device-resident", "rep ")):
                 g.write(line)
     print("wrote", R + "_build_timeline_1m_laplace.txt")
 names = {"bench_rhs1": R + "_bench_1m_laplace_rhs1.json", "bench_rhs8": R + "_bench_1m_laplace_rhs8.json", "bench_rhs16": R + "_bench_1m_laplace_rhs16.json",
@@ -128,6 +128,47 @@ if os.path.exists(os.path.join(F, "buildprof_c3.log")):
         g.write("# python tools/buildprof.py helmholtz 1000000 2   (DEBUG log of the native build: stage@seconds marks, ACA rounds, pack batches; buildprof waits only 3 s between builds, "
                 "so the second build's allocations wait for the driver's wipe of the first one's 207 GB: see `pack` -- the bench line's build_s is the figure without that)\n")
         for line in f:
-            if any(k in line for k in ("timeline", "native build timing", "ACA ", "pack batch", "rep ")):
+            if any(k in line for k in ("timeline", "native build", "ACA ", "pack batch", "device-resident", "rep ")):
                 g.write(line)
     print("wrote", R + "_build_timeline_c3_1m_helmholtz.txt")
+
+# ---- round 4 additions: the reference's default leaf size under the profiler, the cluster tree on the GPU, the 16-wide counter passes
+cp(os.path.join(F, "bench_leaf10_under_rocprof.json"), R + "_bench_1m_laplace_leaf10_under_rocprof.json")
+cp(first(os.path.join(F, "kt_leaf10", "**", "*kernel_stats.csv")), R + "_bench_1m_laplace_leaf10_kernel_stats.csv")
+cp(first(os.path.join(F, "fetch_leaf10", "**", "*counter_collection.csv")), R + "_pmc_leaf10_fetch_size_counter_collection.csv")
+if os.path.exists(os.path.join(F, "buildprof_leaf10.log")):
+    with open(os.path.join(F, "buildprof_leaf10.log")) as f, open(os.path.join(P, R + "_build_timeline_1m_laplace_leaf10.txt"), "w") as g:
+        g.write("# python tools/buildprof.py laplace 1000000 3 1e-3 10   (the reference's default maximal_leaf_size; DEBUG log of the native build)\n")
+        for line in f:
+            if any(k in line for k in ("timeline", "native build", "ACA ", "pack batch", "device-resident", "rep ")):
+                g.write(line)
+    print("wrote", R + "_build_timeline_1m_laplace_leaf10.txt")
+cp(os.path.join(F, "cluster_tree_1m.log"), R + "_cluster_tree_1m_device_vs_host.txt")
+for src, dst in {"bench_2m": R + "_bench_2m_laplace.json", "bench_200k_one_rank_2threads": R + "_bench_200k_one_rank_2_host_threads.json",
+                 "bench_trans_T_rhs16": R + "_bench_1m_laplace_transposed_rhs16.json", "bench_sym_rhs16": R + "_bench_1m_laplace_sym_one_triangle_rhs16.json"}.items():
+    cp(os.path.join(F2, src + ".json"), dst)
+pmc16 = os.path.join(ROOT, "gpurun_out", "r04pmc16")
+if os.path.isdir(pmc16):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_kernel_table.py"), pmc16, "tile_gemm_wide16", "tile_gemm_tall16", "finish_sym16", "reduce_partials16", "gather_x16"],
+                         capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(P, R + "_pmc_wide16_sweeps.txt"), "w") as f:
+        f.write("# rocprofv3 --pmc passes (tools/sessions/r04_pmc_wide16.sh, taken BEFORE the slab-stride / finishing-pass changes of round 4) over the 16-wide sweeps of the\n"
+                "# 1 M-point Laplace operator: sym16 = --symmetric one-triangle --rhs 16, wide16 = --rhs 16, trans16 = --trans T --rhs 16.  Mean counter values per launch;\n"
+                "# SQ_* wave counters in quad-cycles summed over all waves, FETCH_SIZE / WRITE_SIZE in KB as reported (16-byte-per-lane streams: read bytes = 2 x FETCH_SIZE).\n")
+        f.write(out)
+    print("derived", R + "_pmc_wide16_sweeps.txt")
+for name in ("r04w16", "r04tb"):
+    d = os.path.join(ROOT, "gpurun_out", name)
+    if os.path.isdir(d):
+        lines = []
+        for path in sorted(glob.glob(os.path.join(d, "*.json"))):
+            try:
+                j = json.loads(open(path).read().strip().splitlines()[-1])
+                r = j["roofline"]
+                lines.append("%-22s ms/step %8.3f  dominant interval %9.1f us  frac %.3f  %s" % (os.path.basename(path)[:-5], j["ms_per_step"], r["launch_us"], r["frac"], r["kernel"][:60]))
+            except Exception as e:
+                lines.append("%-22s unreadable (%s)" % (os.path.basename(path), e))
+        with open(os.path.join(P, "r04_%s.txt" % {"r04w16": "wide16_after_changes", "r04tb": "tile_order_blocks_ab"}[name]), "w") as f:
+            f.write("# bench.py --no-cpu-baseline --no-warm-build lines of tools/sessions/%s (1 M-point Laplace); *_xcd / *_blocks: HTOOL_TILE_ORDER\n" % {"r04w16": "r04_wide16_ab.sh", "r04tb": "r04_tile_blocks_ab.sh"}[name])
+            f.write("\n".join(lines) + "\n")
+        print("wrote summary of", name)
