@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-R = "r03"  # the round whose final evidence is checked
+R = "r04"  # the round whose final evidence is checked
 
 
 def _line(name):
