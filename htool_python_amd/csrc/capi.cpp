@@ -281,6 +281,7 @@ static htool_hmatrix *build_hmatrix(const htool_generator *g, const htool_cluste
                         "trees, or a partition) cannot use one-triangle storage -- the other triangle would be lost");
         else if (params->symmetry != 'N') log_message(LOG_DEBUG, "symmetric build restricted to a partition or on two cluster trees: both triangles of the requested rows are stored");
     }
+    if (params->transposed_products && !H.one_triangle) H.transposable = true; // (the layout of every batch then carries the slots of the transposed use)
     if (target_partition >= 0) {
         HM_CHECK(target_partition < (int)T->part_nodes.size(), "target_partition_number out of range");
         H.t_root = T->part_nodes[target_partition];

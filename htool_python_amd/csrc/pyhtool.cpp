@@ -702,6 +702,8 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
              "Extension (htool_build_params.aca_confirm_steps).  0 (default): the reference's stopping rule of the partially pivoted ACA.  c > 0: a leaf is "
              "accepted only after c further pivot steps have passed the stopping test too; the confirming terms are dropped, so leaves on which the test "
              "was right keep exactly their factors -- a safeguard for nearly collinear point clouds, where partial pivoting can stop far too early.")
+        .def("set_transposed_products", [](B &b, bool at_build) { b.p.transposed_products = at_build ? 1 : 0; }, "at_build"_a = true,
+             "Extension: lay the index tables of the transposed product (H^T x, H^H x) out during the build instead of at the first such product")
         .def("set_symmetric_storage", [](B &b, bool one_triangle) { b.p.store_one_triangle = one_triangle ? 1 : 0; }, "one_triangle"_a,
              "True (default): symmetry 'S'/'H' keeps the UPLO triangle only, as the reference does; every product uses each stored leaf "
              "twice in one fused sweep (half the memory, about 1.5x faster per vector above ~20 000 unknowns).  False: both triangles "

@@ -143,6 +143,11 @@ typedef struct htool_build_params {
      * confirming step finds a large term (nearly collinear clouds, where partial pivoting can stop far too early:
      * profiles/r03_fuzz_sheet_case_61_322.txt).  Costs one more pivot step per leaf and unit of c.  0 .. 8. */
     int aca_confirm_steps;
+    /* 1: the index tables of the transposed product y = H^T x / H^H x (htool_hmatrix_matvec with trans = 'T' / 'C'; the trans argument
+     * of lu_solve and of the local-operator hooks, hmatrix/hmatrix.hpp:64-78) are laid out and written by the build itself: + 0.5 % of
+     * panel memory, one more coefficient slot per panel column.  0 (default): they are made by the first transposed product
+     * (about 0.5 s at 10^6 points, once).  Ignored for one-triangle storage (which carries them anyway). */
+    int transposed_products;
 } htool_build_params;
 void htool_build_params_default(htool_build_params *p);
 

@@ -13,7 +13,7 @@ class BuildParams(ctypes.Structure):
                 ("reqrank", ctypes.c_int), ("minimal_target_depth", ctypes.c_int), ("minimal_source_depth", ctypes.c_int),
                 ("block_tree_consistency", ctypes.c_int), ("compress", ctypes.c_void_p), ("compress_ctx", ctypes.c_void_p),
                 ("dense_blocks", ctypes.c_void_p), ("dense_blocks_ctx", ctypes.c_void_p), ("compress_borrows", ctypes.c_int),
-                ("store_one_triangle", ctypes.c_int), ("aca_confirm_steps", ctypes.c_int)]
+                ("store_one_triangle", ctypes.c_int), ("aca_confirm_steps", ctypes.c_int), ("transposed_products", ctypes.c_int)]
 
 
 def test_c_abi_end_to_end(built, oracle):
