@@ -29,6 +29,9 @@ def test_single_rank_line(built):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["launches_averaged"] >= 4 and rf["launch_us"] > 0
+    # round 4: the set-up figures say what they are (second / first tree and build of the process, library warm-up before them)
+    assert 0 < d["cluster_tree_s"] <= d["cluster_tree_cold_s"] + 0.05 and abs(d["setup_s"] - (d["cluster_tree_s"] + d["build_s"])) < 1e-9
+    assert d["warm_up_s"] >= 0 and d["host_threads"] >= 1 and "timeline" in (d["build_breakdown"] or "")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "GB/s" and cb["value"] > 0 and cb["cores"] >= 1 and "leaves" in cb["sample"]
 
@@ -42,3 +45,4 @@ def test_two_rank_line_rehearsal(built):
               "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "60001", "--backend", "gloo", "--check"])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "rows2"
     assert d["rel_err_sampled_rows"] < 1e-3
+    assert len(d["per_rank"]) == 2 and all(r["host_threads"] >= 1 and r["cluster_tree_s"] > 0 and abs(r["setup_s"] - (r["cluster_tree_s"] + r["build_s"])) < 1e-9 for r in d["per_rank"])
