@@ -352,6 +352,20 @@ int htool_hmatrix_build_from_leaves(const htool_cluster *target_root, const htoo
     *out = build_hmatrix(nullptr, target_root, source_root, params, target_partition_number, -1, &ps);
     API_END
 }
+int htool_debug_scan_positions(const int *counts_dev, int64_t n, int64_t *positions_dev, int64_t *totals2) {
+    API_BEGIN
+    HM_CHECK(n >= 0 && (n == 0 || (counts_dev && positions_dev)) && totals2, "htool_debug_scan_positions: bad argument");
+    long long t[2] = {0, 0};
+    device_debug_positions(counts_dev, (long long)n, (long long *)positions_dev, t);
+    totals2[0] = t[0]; totals2[1] = t[1];
+    API_END
+}
+int htool_debug_sort_pairs(uint32_t *keys_dev, uint32_t *values_dev, int64_t n, int key_bits) {
+    API_BEGIN
+    HM_CHECK(n >= 0 && (n == 0 || (keys_dev && values_dev)) && key_bits >= 1 && key_bits <= 32, "htool_debug_sort_pairs: bad argument");
+    device_debug_sort_pairs(keys_dev, values_dev, (long long)n, key_bits);
+    API_END
+}
 int htool_hmatrix_is_one_triangle(const htool_hmatrix *h) { return h->H.one_triangle ? 1 : 0; }
 void htool_hmatrix_destroy(htool_hmatrix *h) { delete h; }
 int htool_hmatrix_clone(const htool_hmatrix *h, htool_hmatrix **out) {

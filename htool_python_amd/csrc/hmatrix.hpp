@@ -202,5 +202,8 @@ void device_set_phase_timing(const HMatrix &H, bool on);
 void device_free(DeviceHMatrix *d);
 size_t device_release_workspace(); // frees the cached temporary buffers (build arena ...); returns the bytes freed
 size_t device_workspace_bytes();
+// unit-test entries of the scan / sort primitives of the device-resident build (device_scan.inc)
+void device_debug_positions(const int *counts_dev, long long n, long long *pos_dev, long long totals[2]);
+void device_debug_sort_pairs(unsigned *keys_dev, unsigned *vals_dev, long long n, int bits);
 
 } // namespace hm

@@ -349,6 +349,14 @@ int htool_distributed_exchange_kind(const htool_distributed *d, int mu);
 int htool_debug_compact_slices(const void *gathered_dev, void *x_full_dev, const int *counts, const int *displs, int P, int pad, int mu, int64_t ldx,
                                int is_complex, void *stream);
 
+/* diagnostic entries for the unit tests of the two primitives the device-resident build stands on (csrc/device_scan.inc; the
+ * block tree of hmatrix_tree_builder.hpp:36 is flattened with them).  htool_debug_scan_positions: element i asks for
+ * counts[2 i] places in one output stream and counts[2 i + 1] in another; positions[2 i], positions[2 i + 1] receive the
+ * exclusive prefix sums IN ELEMENT ORDER, totals2 the two sums.  htool_debug_sort_pairs: stable sort of n (key, value) pairs by
+ * the low key_bits bits of the key, in place.  Device arrays. */
+int htool_debug_scan_positions(const int *counts_dev, int64_t n, int64_t *positions_dev, int64_t *totals2);
+int htool_debug_sort_pairs(uint32_t *keys_dev, uint32_t *values_dev, int64_t n, int key_bits);
+
 /* ---- Krylov helper (solver/solver.hpp:22-65: the reference hands the operator to HPDDM; this package runs its own GMRES on
  * device-resident vectors, htool_python_amd/krylov.py) -------------------------------------------------------------------
  * The tail of an Arnoldi step with classical Gram-Schmidt applied twice, as ONE launch on `stream`.  Basis layout: vector l of
