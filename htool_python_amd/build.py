@@ -20,10 +20,10 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 ARCH = "gfx950"
 
-HOST_SOURCES = ["util.cpp", "cluster.cpp", "blocktree.cpp", "layout.cpp", "build_host.cpp", "capi.cpp"]
-HIP_SOURCES = ["device.hip", "dist_device.hip", "krylov_device.hip", "dense_device.hip", "cluster_device.hip"]
+HOST_SOURCES = ["util.cpp", "cluster.cpp", "blocktree.cpp", "layout.cpp", "build_host.cpp", "capi.cpp", "hlu_symbolic.cpp", "hlu_capi.cpp"]
+HIP_SOURCES = ["device.hip", "dist_device.hip", "krylov_device.hip", "dense_device.hip", "cluster_device.hip", "hlu_device.hip"]
 HEADERS = ["common.hpp", "cluster.hpp", "hmatrix.hpp", "device_internal.hpp", "capi_internal.hpp", "device_build.inc", "device_aca_wave.inc", "device_aca_steps.inc", "aca_stop.hpp", "device_recompress.inc", "device_expand.inc", "product_kernels.inc", "product_mfma.inc", "pack_kernels.inc", "device_memory.inc",
-           "device_tables.inc", os.path.join("..", "..", "include", "htool_mi355x.h")]
+           "device_tables.inc", "hlu.hpp", os.path.join("..", "..", "include", "htool_mi355x.h")]
 
 
 def ext_path():

@@ -27,6 +27,19 @@ void device_dense_solve(const DeviceDenseFactor *f, char trans, void *B_dev, lon
 void device_dense_solve_host(const hm::HMatrix &H, const DeviceDenseFactor *f, char trans, void *B, int mu);
 void device_dense_factor_free(DeviceDenseFactor *f);
 int device_dense_factor_kind(const DeviceDenseFactor *f);
+// hierarchical LU (hlu.hpp): the plan handle of the diagnostic entries, and the device factorisation (hlu_device.hip)
+namespace hm { namespace hlu { struct Plan; } }
+struct htool_hlu_plan {
+    hm::hlu::Plan *plan = nullptr;
+    ~htool_hlu_plan(); // hlu_capi.cpp
+};
+struct DeviceHLU;
+DeviceHLU *device_hlu_factor(const hm::HMatrix &H, int kind, double shift, double eps_lu);
+void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb, int mu, void *stream);
+void device_hlu_solve_host(const hm::HMatrix &H, const DeviceHLU *f, char trans, void *B, int mu);
+void device_hlu_free(DeviceHLU *f);
+int device_hlu_kind(const DeviceHLU *f);
+void device_hlu_stats(const DeviceHLU *f, int64_t *out16, double *seconds4);
 struct DistDeviceState; // device-side exchange buffers of a distributed operator (dist_device.hip)
 struct htool_distributed {
     htool_hmatrix *hmat = nullptr;

@@ -1,0 +1,783 @@
+// hlu_device.hip -- hierarchical LU on the device: the executor of the plan of hlu_symbolic.cpp (see hlu.hpp).
+//
+// Stands where the reference calls htool::lu_factorization / lu_solve / cholesky_factorization / cholesky_solve
+// (bound at src/htool/hmatrix/hmatrix.hpp:58-94).  The leaves of the operator are unpacked from the product's tile
+// panels into one FACTOR ARENA (dense leaf: m x n column-major; low-rank leaf: U m x cap and V n x cap, `cap` columns
+// of room), the plan's windows are uploaded one after the other and every (level, kind) bucket of a window is ONE
+// launch: a workgroup per task -- or per run of updates of one target leaf, executed in plan order, so that nothing is
+// accumulated by atomics and the factors are bitwise reproducible.  Kernels (fp64, HBM / latency bound: the leaves are
+// small, the arithmetic intensity is that of thin products):
+//   hlu_fill_kernel         zero a scratch block
+//   hlu_apply_dense_kernel  Y (+)= -+ op(M) X, M a dense leaf or the inverse factor of a diagonal leaf (in place for the latter)
+//   hlu_apply_lr_kernel     Y (+)= -+ A (B^T X), (A, B) the rows of the two factors of a low-rank leaf restricted to a sub-block
+//   hlu_update_kernel       the updates of ONE target leaf: dense D -= X Z^T; low rank: columns appended, the leaf re-truncated
+//                           when its room is used up (and by FINAL tasks): Gram matrices of both factors, their
+//                           eigen-decompositions and the SVD of the small core by one-sided Jacobi rotations in LDS
+//                           (round-robin pairs, eight lanes per pair), the two K x r transforms applied row by row
+//   hlu_ddprod_kernel       product of two dense leaves that lands in a low-rank leaf: formed in a work block, compressed by
+//                           cross approximation with full pivoting on the explicit residual, handed on as X' Z'^T
+//   hlu_getrf_kernel        LU with partial pivoting of a diagonal leaf + the explicit inverses (P^T L)^-1 and U^-1, with
+//                           which every triangular solve against a diagonal leaf is a product
+// lu_solve replays the plan's solve program (forward and backward sweep over the leaves) on the caller's block of
+// right-hand sides.
+#include <algorithm>
+#include <cstring>
+
+#include "capi_internal.hpp"
+#include "device_internal.hpp"
+#include "hlu.hpp"
+
+using namespace hm;
+using namespace hm::hlu;
+
+namespace {
+
+constexpr int QC = 8;           // right-hand-side columns per pass of the apply kernels
+constexpr int HLU_MAX_DIM = 1024; // rows / columns of a dense leaf the apply kernels stage in LDS
+
+struct Ctx {
+    double *space[4];
+    long long ld_rhs;
+    int nrhs;
+    const Leaf *leaves;
+    const Diag *diags;
+    int *rank;
+    double *norm0, *norm2;
+    double eps;
+    long long *counters; // [0] forced truncations, [1] truncations, [2] appended columns, [3] columns out of dense products, [4] zero pivots
+};
+
+__device__ __forceinline__ double *at(const Ctx &c, long long ref) { return c.space[(int)(ref >> SPACE_SHIFT)] + (ref & (((long long)1 << SPACE_SHIFT) - 1)); }
+__device__ __forceinline__ int cols_of(const Ctx &c, const Task &t) { return t.kref >= 0 ? c.rank[t.kref] : t.kref == -1 ? t.kconst : c.nrhs; }
+__device__ __forceinline__ long long ld_of(const Ctx &c, long long ref, int ld) { return (int)(ref >> SPACE_SHIFT) == SP_RHS ? c.ld_rhs : (long long)ld; }
+
+__global__ __launch_bounds__(256) void hlu_fill_kernel(Ctx c, const Task *tasks) {
+    const Task t = tasks[blockIdx.x];
+    const int q = cols_of(c, t);
+    double *y = at(c, t.y);
+    const long long ld = ld_of(c, t.y, t.y_ld);
+    for (long long e = threadIdx.x; e < (long long)q * t.m; e += 256) {
+        const int col = (int)(e / t.m), i = (int)(e - (long long)col * t.m);
+        y[i + col * ld] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void hlu_apply_dense_kernel(Ctx c, const Task *tasks) {
+    extern __shared__ double sm[]; // n x QC
+    const Task t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, q = cols_of(c, t);
+    const double *M = at(c, t.a), *x = at(c, t.x);
+    double *y = at(c, t.y);
+    const long long xl = ld_of(c, t.x, t.x_ld), yl = ld_of(c, t.y, t.y_ld);
+    const bool tr = t.flags & F_TRANS, xt = t.flags & F_XT, yt = t.flags & F_YT, acc = t.flags & F_ACCUM;
+    const double alpha = (t.flags & F_SUB) ? -1.0 : 1.0;
+    for (int c0 = 0; c0 < q; c0 += QC) {
+        const int qc = min(QC, q - c0);
+        __syncthreads();
+        for (int e = tid; e < t.n * QC; e += 256) {
+            int i, col;
+            if (xt) { col = e % QC; i = e / QC; } else { i = e % t.n; col = e / t.n; }
+            sm[i * QC + col] = col < qc ? (xt ? x[(long long)i * xl + c0 + col] : x[i + (long long)(c0 + col) * xl]) : 0.0;
+        }
+        __syncthreads();
+        for (int i = tid; i < t.m; i += 256) {
+            double a[QC];
+#pragma unroll
+            for (int col = 0; col < QC; col++) a[col] = 0.0;
+            if (!tr) {
+                for (int j = 0; j < t.n; j++) {
+                    const double mv = M[i + (long long)j * t.a_ld];
+#pragma unroll
+                    for (int col = 0; col < QC; col++) a[col] = fma(mv, sm[j * QC + col], a[col]);
+                }
+            } else {
+                const double *Mi = M + (long long)i * t.a_ld;
+                for (int j = 0; j < t.n; j++) {
+                    const double mv = Mi[j];
+#pragma unroll
+                    for (int col = 0; col < QC; col++) a[col] = fma(mv, sm[j * QC + col], a[col]);
+                }
+            }
+#pragma unroll
+            for (int col = 0; col < QC; col++)
+                if (col < qc) {
+                    double *dst = yt ? y + (long long)i * yl + c0 + col : y + i + (long long)(c0 + col) * yl;
+                    *dst = acc ? *dst + alpha * a[col] : alpha * a[col];
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hlu_apply_lr_kernel(Ctx c, const Task *tasks) {
+    __shared__ double W[64 * QC];
+    __shared__ double red[4][64];
+    const Task t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = cols_of(c, t), k = c.rank[t.leaf];
+    const double *A = at(c, t.a), *B = at(c, t.b), *x = at(c, t.x);
+    double *y = at(c, t.y);
+    const long long xl = ld_of(c, t.x, t.x_ld), yl = ld_of(c, t.y, t.y_ld);
+    const bool acc = t.flags & F_ACCUM;
+    const double alpha = (t.flags & F_SUB) ? -1.0 : 1.0;
+    if (k == 0) {
+        if (!acc) for (long long e = tid; e < (long long)q * t.m; e += 256) { const int col = (int)(e / t.m), i = (int)(e - (long long)col * t.m); y[i + col * yl] = 0.0; }
+        return;
+    }
+    for (int c0 = 0; c0 < q; c0 += QC) {
+        const int qc = min(QC, q - c0);
+        for (int l0 = 0; l0 < k; l0 += 8) { // W[l0 .. l0 + 8) = B^T X
+            double a[8][QC];
+#pragma unroll
+            for (int l = 0; l < 8; l++)
+#pragma unroll
+                for (int col = 0; col < QC; col++) a[l][col] = 0.0;
+            for (int j = tid; j < t.n; j += 256) {
+                double xv[QC];
+#pragma unroll
+                for (int col = 0; col < QC; col++) xv[col] = col < qc ? x[j + (long long)(c0 + col) * xl] : 0.0;
+#pragma unroll
+                for (int l = 0; l < 8; l++) {
+                    const double b = l0 + l < k ? B[j + (long long)(l0 + l) * t.b_ld] : 0.0;
+#pragma unroll
+                    for (int col = 0; col < QC; col++) a[l][col] = fma(b, xv[col], a[l][col]);
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < 8; l++)
+#pragma unroll
+                for (int col = 0; col < QC; col++) {
+                    double v = a[l][col];
+                    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+                    if (lane == 0) red[wave][l * 8 + col] = v;
+                }
+            __syncthreads();
+            if (tid < 64 && l0 + tid / 8 < 64) W[(l0 + tid / 8) * QC + (tid & 7)] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            __syncthreads();
+        }
+        for (int i = tid; i < t.m; i += 256) {
+            double s[QC];
+#pragma unroll
+            for (int col = 0; col < QC; col++) s[col] = 0.0;
+            for (int l = 0; l < k; l++) {
+                const double av = A[i + (long long)l * t.a_ld];
+#pragma unroll
+                for (int col = 0; col < QC; col++) s[col] = fma(av, W[l * QC + col], s[col]);
+            }
+#pragma unroll
+            for (int col = 0; col < QC; col++)
+                if (col < qc) {
+                    double *dst = y + i + (long long)(c0 + col) * yl;
+                    *dst = acc ? *dst + alpha * s[col] : alpha * s[col];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// One-sided Jacobi on the columns of M (K x K in LDS, row stride KS): M <- M J with J accumulated from the identity.  Round-robin
+// pairs: the K / 2 disjoint column pairs of a round are rotated side by side, eight lanes per pair (they split the rows).
+__device__ void jacobi_lds(double *M, double *J, int K, int KS, int *flag) {
+    const int tid = threadIdx.x, g = tid >> 3, sub = tid & 7;
+    const int Kp = (K + 1) & ~1, npairs = Kp / 2;
+    for (int e = tid; e < K * K; e += 256) { const int i = e / K, j = e - i * K; J[i * KS + j] = i == j ? 1.0 : 0.0; }
+    __syncthreads();
+    if (K < 2) return;
+    for (int sweep = 0; sweep < 40; sweep++) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int r = 0; r < Kp - 1; r++) {
+            if (g < npairs) {
+                int p = g == 0 ? Kp - 1 : (r + g) % (Kp - 1), q = g == 0 ? r % (Kp - 1) : (r + Kp - 1 - g) % (Kp - 1);
+                if (p > q) { const int s = p; p = q; q = s; }
+                if (q < K) {
+                    double al = 0, be = 0, ga = 0;
+                    for (int i = sub; i < K; i += 8) { const double x = M[i * KS + p], y = M[i * KS + q]; al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga); }
+                    for (int d = 1; d < 8; d <<= 1) { al += __shfl_xor(al, d); be += __shfl_xor(be, d); ga += __shfl_xor(ga, d); }
+                    if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+                        const double zeta = (be - al) / (2 * ga);
+                        const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                        const double cs = 1 / sqrt(1 + tt * tt), sn = cs * tt;
+                        for (int i = sub; i < K; i += 8) {
+                            double x = M[i * KS + p], y = M[i * KS + q];
+                            M[i * KS + p] = cs * x - sn * y; M[i * KS + q] = sn * x + cs * y;
+                            x = J[i * KS + p]; y = J[i * KS + q];
+                            J[i * KS + p] = cs * x - sn * y; J[i * KS + q] = sn * x + cs * y;
+                        }
+                        if (sub == 0) *flag = 1;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int again = *flag;
+        __syncthreads();
+        if (!again) break;
+    }
+}
+
+__device__ __forceinline__ int keep_max(const Leaf &L) { return L.cap - max(4, L.cap / 4); }
+
+// U V^T with K = rank[l] columns -> the truncated form (hlu.hpp); the whole workgroup.  sm: 4 matrices of Kc x KS, then vectors.
+__device__ void recompress(const Ctx &c, int l, const Leaf &L, double *sm, int Kc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = c.rank[l], m = L.m, n = L.n, KS = Kc + 1;
+    double *U = c.space[0] + L.u, *V = c.space[0] + L.v;
+    double *Gu = sm, *Gv = Gu + Kc * KS, *Eu = Gv + Kc * KS, *Ev = Eu + Kc * KS;
+    double *d = Ev + Kc * KS, *su = d + Kc, *sv = su + Kc, *sig = sv + Kc;
+    int *ord = (int *)(sig + Kc), *flag = ord + Kc, *s_newr = flag + 1;
+    if (K == 0) {
+        if (tid == 0) { c.norm2[l] = 0.0; if (c.norm0[l] < 0) c.norm0[l] = 0.0; }
+        __syncthreads();
+        return;
+    }
+    // Gram matrices, one (a <= b) pair per wave at a time
+    const int npairs = K * (K + 1) / 2;
+    for (int p = wave; p < 2 * npairs; p += 4) {
+        const bool vside = p >= npairs;
+        int q = vside ? p - npairs : p, a = 0;
+        while (q >= K - a) { q -= K - a; a++; }
+        const int b = a + q;
+        const double *x = vside ? V + (long long)a * n : U + (long long)a * m, *y = vside ? V + (long long)b * n : U + (long long)b * m;
+        const int len = vside ? n : m;
+        double s = 0;
+        for (int i = lane; i < len; i += 64) s = fma(x[i], y[i], s);
+        for (int dd = 32; dd > 0; dd >>= 1) s += __shfl_down(s, dd);
+        if (lane == 0) { double *G = vside ? Gv : Gu; G[a * KS + b] = s; G[b * KS + a] = s; }
+    }
+    __syncthreads();
+    if (tid < K) {
+        const double gu = Gu[tid * KS + tid], gv = Gv[tid * KS + tid];
+        d[tid] = (gu > 0 && gv > 0) ? sqrt(sqrt(gv / gu)) : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += 256) {
+        const int a = e / K, b = e - a * K;
+        const double dd = d[a] * d[b];
+        Gu[a * KS + b] *= dd;
+        Gv[a * KS + b] = dd > 0 ? Gv[a * KS + b] / dd : 0.0;
+    }
+    __syncthreads();
+    jacobi_lds(Gu, Eu, K, KS, flag);
+    jacobi_lds(Gv, Ev, K, KS, flag);
+    if (tid < K) {
+        double a = 0, b = 0;
+        for (int i = 0; i < K; i++) { a = fma(Gu[i * KS + tid], Gu[i * KS + tid], a); b = fma(Gv[i * KS + tid], Gv[i * KS + tid], b); }
+        su[tid] = sqrt(sqrt(a)); sv[tid] = sqrt(sqrt(b));
+    }
+    __syncthreads();
+    double lu_max = 0, lv_max = 0;
+    for (int j = 0; j < K; j++) { lu_max = fmax(lu_max, su[j]); lv_max = fmax(lv_max, sv[j]); }
+    __syncthreads();
+    if (tid < K) { if (!(su[tid] > 1e-7 * lu_max)) su[tid] = 0.0; if (!(sv[tid] > 1e-7 * lv_max)) sv[tid] = 0.0; }
+    __syncthreads();
+    for (int e = tid; e < K * K; e += 256) { // core C = S_u E_u^T E_v S_v over Gu
+        const int i = e / K, j = e - i * K;
+        double s = 0;
+        for (int a = 0; a < K; a++) s = fma(Eu[a * KS + i], Ev[a * KS + j], s);
+        Gu[i * KS + j] = su[i] * s * sv[j];
+    }
+    __syncthreads();
+    jacobi_lds(Gu, Gv, K, KS, flag); // C J = W: W over Gu, J over Gv
+    if (tid < K) {
+        double s = 0;
+        for (int i = 0; i < K; i++) s = fma(Gu[i * KS + tid], Gu[i * KS + tid], s);
+        sig[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0;
+        for (int j = 0; j < K; j++) { tot += sig[j]; ord[j] = j; }
+        for (int i = 1; i < K; i++) { // insertion sort, descending, stable
+            const int o = ord[i];
+            int j = i - 1;
+            while (j >= 0 && sig[ord[j]] < sig[o]) { ord[j + 1] = ord[j]; j--; }
+            ord[j + 1] = o;
+        }
+        int newr = K;
+        double tail = 0;
+        for (int k = K - 1; k >= 0; k--) {
+            if (tail + sig[ord[k]] <= c.eps * c.eps * tot) { tail += sig[ord[k]]; newr = k; }
+            else break;
+        }
+        c.counters[1]++;
+        if (newr > keep_max(L)) { newr = keep_max(L); c.counters[0]++; }
+        double kept = 0;
+        for (int q = 0; q < newr; q++) kept += sig[ord[q]];
+        c.norm2[l] = kept;
+        if (c.norm0[l] < 0) c.norm0[l] = kept;
+        *s_newr = newr;
+    }
+    __syncthreads();
+    const int newr = *s_newr;
+    if (tid < K) { // T_u = D E_u S_u^-1 W[:, sel] over row tid of Eu;  T_v = D^-1 E_v S_v^-1 J[:, sel] over row tid of Ev
+        double row[64];
+        const double da = d[tid];
+        for (int i = 0; i < K; i++) row[i] = su[i] > 0 ? Eu[tid * KS + i] / su[i] : 0.0;
+        for (int q = 0; q < newr; q++) {
+            double s = 0;
+            for (int i = 0; i < K; i++) s = fma(row[i], Gu[i * KS + ord[q]], s);
+            Eu[tid * KS + q] = da * s;
+        }
+        for (int i = 0; i < K; i++) row[i] = sv[i] > 0 ? Ev[tid * KS + i] / sv[i] : 0.0;
+        for (int q = 0; q < newr; q++) {
+            double s = 0;
+            for (int i = 0; i < K; i++) s = fma(row[i], Gv[i * KS + ord[q]], s);
+            Ev[tid * KS + q] = da > 0 ? s / da : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) {
+        double row[64];
+        for (int k = 0; k < K; k++) row[k] = U[(long long)k * m + i];
+        for (int q = 0; q < newr; q++) {
+            double s = 0;
+            for (int k = 0; k < K; k++) s = fma(row[k], Eu[k * KS + q], s);
+            U[(long long)q * m + i] = s;
+        }
+    }
+    for (int i = tid; i < n; i += 256) {
+        double row[64];
+        for (int k = 0; k < K; k++) row[k] = V[(long long)k * n + i];
+        for (int q = 0; q < newr; q++) {
+            double s = 0;
+            for (int k = 0; k < K; k++) s = fma(row[k], Ev[k * KS + q], s);
+            V[(long long)q * n + i] = s;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) c.rank[l] = newr;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void hlu_update_kernel(Ctx c, const Task *tasks, const long long *seg, int Kc) {
+    extern __shared__ double sm[];
+    const int tid = threadIdx.x;
+    const long long first = seg[blockIdx.x], last = seg[blockIdx.x + 1];
+    for (long long ti = first; ti < last; ti++) {
+        const Task t = tasks[ti];
+        const Leaf L = c.leaves[t.leaf];
+        if (t.type == T_FINAL) { recompress(c, t.leaf, L, sm, Kc); continue; }
+        const int k = cols_of(c, t);
+        const double *X = at(c, t.x), *Z = at(c, t.y);
+        const bool xt = t.flags & F_XT, zt = t.flags & F_YT;
+        const double alpha = (t.flags & F_SUB) ? -1.0 : 1.0;
+        if (L.kind == 0) {
+            double *D = c.space[0] + L.u;
+            for (int e = tid; e < t.m * t.n; e += 256) {
+                const int i = e % t.m, j = e / t.m;
+                double s = 0;
+                for (int q = 0; q < k; q++) {
+                    const double xv = xt ? X[(long long)i * t.x_ld + q] : X[i + (long long)q * t.x_ld];
+                    const double zv = zt ? Z[(long long)j * t.y_ld + q] : Z[j + (long long)q * t.y_ld];
+                    s = fma(xv, zv, s);
+                }
+                D[(t.r0 + i) + (long long)(t.c0 + j) * L.m] += alpha * s;
+            }
+            __syncthreads();
+            continue;
+        }
+        double *U = c.space[0] + L.u, *V = c.space[0] + L.v;
+        int done = 0;
+        while (done < k) {
+            int fill = c.rank[t.leaf];
+            if (fill >= L.cap) { recompress(c, t.leaf, L, sm, Kc); fill = c.rank[t.leaf]; }
+            const int take = min(k - done, L.cap - fill);
+            for (long long e = tid; e < (long long)take * L.m; e += 256) {
+                const int col = (int)(e / L.m), i = (int)(e - (long long)col * L.m), r = i - t.r0, q = done + col;
+                U[(long long)(fill + col) * L.m + i] = (r >= 0 && r < t.m) ? alpha * (xt ? X[(long long)r * t.x_ld + q] : X[r + (long long)q * t.x_ld]) : 0.0;
+            }
+            for (long long e = tid; e < (long long)take * L.n; e += 256) {
+                const int col = (int)(e / L.n), j = (int)(e - (long long)col * L.n), r = j - t.c0, q = done + col;
+                V[(long long)(fill + col) * L.n + j] = (r >= 0 && r < t.n) ? (zt ? Z[(long long)r * t.y_ld + q] : Z[r + (long long)q * t.y_ld]) : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) { c.rank[t.leaf] = fill + take; c.counters[2] += take; }
+            __syncthreads();
+            done += take;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hlu_ddprod_kernel(Ctx c, const Task *tasks) {
+    __shared__ double rfro[256], rbest[256];
+    __shared__ int ridx[256];
+    __shared__ int s_stop;
+    const Task t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, m = t.m, n = t.n, qn = t.r0;
+    const double *A = at(c, t.a), *B = at(c, t.b);
+    double *W = at(c, t.w), *X = at(c, t.x), *Z = at(c, t.y);
+    for (int e = tid; e < m * n; e += 256) {
+        const int i = e % m, j = e / m;
+        double s = 0;
+        for (int l = 0; l < qn; l++) s = fma(A[i + (long long)l * t.a_ld], B[l + (long long)j * t.b_ld], s);
+        W[e] = s;
+    }
+    __syncthreads();
+    const double tol2 = 0.01 * c.eps * c.eps * fmax(c.norm0[t.leaf], 0.0);
+    int k = 0;
+    while (k < t.kconst) {
+        double fro = 0, best = 0;
+        int bidx = 0;
+        for (int e = tid; e < m * n; e += 256) { const double v = W[e]; fro = fma(v, v, fro); if (fabs(v) > best) { best = fabs(v); bidx = e; } }
+        rfro[tid] = fro; rbest[tid] = best; ridx[tid] = bidx;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                rfro[tid] += rfro[tid + s];
+                if (rbest[tid + s] > rbest[tid] || (rbest[tid + s] == rbest[tid] && ridx[tid + s] < ridx[tid])) { rbest[tid] = rbest[tid + s]; ridx[tid] = ridx[tid + s]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_stop = (rfro[0] <= tol2 || rbest[0] == 0.0) ? 1 : 0;
+        __syncthreads();
+        if (s_stop) break;
+        const int pidx = ridx[0], bi = pidx % m, bj = pidx / m;
+        const double piv = W[pidx];
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) X[i + (long long)k * t.x_ld] = W[i + (long long)bj * m] / piv;
+        for (int j = tid; j < n; j += 256) Z[j + (long long)k * t.y_ld] = W[bi + (long long)j * m];
+        __syncthreads();
+        for (int e = tid; e < m * n; e += 256) { const int i = e % m, j = e / m; W[e] -= X[i + (long long)k * t.x_ld] * Z[j + (long long)k * t.y_ld]; }
+        __syncthreads();
+        k++;
+    }
+    if (tid == 0) { c.rank[t.kref] = k; c.counters[3] += k; }
+}
+
+__global__ __launch_bounds__(256) void hlu_getrf_kernel(Ctx c, const Task *tasks) {
+    extern __shared__ int piv[];
+    __shared__ double rbest[256];
+    __shared__ int ridx[256];
+    const Task t = tasks[blockIdx.x];
+    const Leaf L = c.leaves[t.leaf];
+    const Diag Dg = c.diags[L.diag];
+    const int tid = threadIdx.x, m = L.m;
+    double *A = c.space[0] + L.u, *Li = c.space[1] + Dg.linv, *Ui = c.space[1] + Dg.uinv;
+    for (int j = 0; j < m; j++) {
+        double best = -1.0;
+        int bi = j;
+        for (int i = j + tid; i < m; i += 256) { const double v = fabs(A[i + (long long)j * m]); if (v > best) { best = v; bi = i; } }
+        rbest[tid] = best; ridx[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s && (rbest[tid + s] > rbest[tid] || (rbest[tid + s] == rbest[tid] && ridx[tid + s] < ridx[tid]))) { rbest[tid] = rbest[tid + s]; ridx[tid] = ridx[tid + s]; }
+            __syncthreads();
+        }
+        const int p = ridx[0];
+        if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) c.counters[4]++; }
+        __syncthreads();
+        if (p != j) for (int col = tid; col < m; col += 256) { const double a = A[j + (long long)col * m]; A[j + (long long)col * m] = A[p + (long long)col * m]; A[p + (long long)col * m] = a; }
+        __syncthreads();
+        const double dinv = A[j + (long long)j * m];
+        __syncthreads();
+        for (int i = j + 1 + tid; i < m; i += 256) A[i + (long long)j * m] /= dinv;
+        __syncthreads();
+        const int nn = m - j - 1;
+        for (int e = tid; e < nn * nn; e += 256) {
+            const int i = j + 1 + e % nn, col = j + 1 + e / nn;
+            A[i + (long long)col * m] -= A[i + (long long)j * m] * A[j + (long long)col * m];
+        }
+        __syncthreads();
+    }
+    for (int col = tid; col < m; col += 256) { // (P^T L)^-1 = L^-1 P and U^-1, a column per thread
+        double *y = Li + (long long)col * m;
+        for (int i = 0; i < m; i++) y[i] = i == col ? 1.0 : 0.0;
+        for (int j = 0; j < m; j++) if (piv[j] != j) { const double a = y[j]; y[j] = y[piv[j]]; y[piv[j]] = a; }
+        for (int j = 0; j < m; j++) {
+            const double yj = y[j];
+            if (yj != 0.0) for (int i = j + 1; i < m; i++) y[i] -= A[i + (long long)j * m] * yj;
+        }
+        double *z = Ui + (long long)col * m;
+        for (int i = 0; i < m; i++) z[i] = i == col ? 1.0 : 0.0;
+        for (int j = col; j >= 0; j--) {
+            z[j] /= A[j + (long long)j * m];
+            const double zj = z[j];
+            for (int i = 0; i < j; i++) z[i] -= A[i + (long long)j * m] * zj;
+        }
+    }
+}
+
+__global__ void hlu_shift_kernel(Ctx c, int n_diag, double shift) {
+    const int dgi = blockIdx.x;
+    if (dgi >= n_diag) return;
+    const Leaf L = c.leaves[c.diags[dgi].leaf];
+    double *A = c.space[0] + L.u;
+    for (int i = threadIdx.x; i < L.m; i += blockDim.x) A[i + (long long)i * L.m] += shift;
+}
+// the leaf (s, t) of an operator that stores one triangle: the transpose of the stored leaf (t, s)
+__global__ __launch_bounds__(256) void hlu_mirror_kernel(Ctx c, const int2 *pairs, int rank_known) {
+    const Leaf S = c.leaves[pairs[blockIdx.x].x], M = c.leaves[pairs[blockIdx.x].y];
+    double *F = c.space[0];
+    if (S.kind == 0) {
+        for (int e = threadIdx.x; e < S.m * S.n; e += 256) { const int i = e % S.m, j = e / S.m; F[M.u + j + (long long)i * M.m] = F[S.u + e]; }
+        return;
+    }
+    const int k = c.rank[pairs[blockIdx.x].x];
+    for (long long e = threadIdx.x; e < (long long)k * S.m; e += 256) F[M.v + e] = F[S.u + e];
+    for (long long e = threadIdx.x; e < (long long)k * S.n; e += 256) F[M.u + e] = F[S.v + e];
+    if (threadIdx.x == 0) c.rank[pairs[blockIdx.x].y] = k;
+    (void)rank_known;
+}
+template <typename T>
+__global__ void hlu_permute_rows_kernel(const T *src, T *dst, const int *perm, int n, int mu, int gather) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)n * mu) return;
+    const int col = (int)(e / n), i = (int)(e - (long long)col * n);
+    if (gather) dst[e] = src[(long long)col * n + perm[i]];
+    else dst[(long long)col * n + perm[i]] = src[e];
+}
+
+size_t update_lds_bytes(int Kc) { return (size_t)(4 * Kc * (Kc + 1) + 4 * Kc) * sizeof(double) + (size_t)(Kc + 8) * sizeof(int); }
+
+struct DevProgram {
+    Task *tasks = nullptr;
+    long long *seg = nullptr;
+    size_t n_tasks = 0, n_seg = 0;
+};
+
+void attributes_once() {
+    static bool done = false;
+    if (done) return;
+    HIP_OK(hipFuncSetAttribute((const void *)hlu_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)update_lds_bytes(64)));
+    HIP_OK(hipFuncSetAttribute((const void *)hlu_apply_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HLU_MAX_DIM * QC * (int)sizeof(double)));
+    done = true;
+}
+
+// one program, bucket by bucket, on `st`; tasks / runs already on the device
+void run_program(const Program &G, const DevProgram &dp, const Ctx &c, const std::vector<Leaf> &leaves, hipStream_t st) {
+    attributes_once();
+    for (const Bucket &b : G.buckets) {
+        const unsigned n = (unsigned)(b.end - b.begin);
+        const Task *t0 = dp.tasks + b.begin;
+        switch (b.type) {
+        case T_FILL: hipLaunchKernelGGL(hlu_fill_kernel, dim3(n), dim3(256), 0, st, c, t0); break;
+        case T_APPLY_DENSE: {
+            int nmax = 1;
+            for (int64_t i = b.begin; i < b.end; i++) nmax = std::max(nmax, G.tasks[(size_t)i].n);
+            HM_CHECK(nmax <= HLU_MAX_DIM, "hierarchical LU: a dense leaf has more rows or columns than the kernels stage on chip");
+            hipLaunchKernelGGL(hlu_apply_dense_kernel, dim3(n), dim3(256), (size_t)nmax * QC * sizeof(double), st, c, t0);
+            break;
+        }
+        case T_APPLY_LR: hipLaunchKernelGGL(hlu_apply_lr_kernel, dim3(n), dim3(256), 0, st, c, t0); break;
+        case T_ADDLR:
+        case T_FINAL: {
+            int Kc = 2;
+            for (int64_t i = b.begin; i < b.end; i++) Kc = std::max(Kc, leaves[(size_t)G.tasks[(size_t)i].leaf].cap);
+            hipLaunchKernelGGL(hlu_update_kernel, dim3((unsigned)(b.seg_end - b.seg_begin)), dim3(256), update_lds_bytes(Kc), st, c, dp.tasks, dp.seg + b.seg_begin, Kc);
+            break;
+        }
+        case T_DDPROD: hipLaunchKernelGGL(hlu_ddprod_kernel, dim3(n), dim3(256), 0, st, c, t0); break;
+        case T_GETRF: {
+            int mmax = 1;
+            for (int64_t i = b.begin; i < b.end; i++) mmax = std::max(mmax, G.tasks[(size_t)i].m);
+            hipLaunchKernelGGL(hlu_getrf_kernel, dim3(n), dim3(256), (size_t)mmax * sizeof(int), st, c, t0);
+            break;
+        }
+        default: throw Error("hierarchical LU: unknown task kind");
+        }
+    }
+    HIP_OK(hipGetLastError());
+}
+
+struct DevBuf { // device allocation released on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    void alloc(size_t bytes) { HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16))); }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+void upload_program(const Program &G, DevBuf &tasks, DevBuf &seg, DevProgram &dp, hipStream_t st) {
+    dp.n_tasks = G.tasks.size(); dp.n_seg = G.seg.size();
+    dp.tasks = tasks.as<Task>(); dp.seg = seg.as<long long>();
+    if (!G.tasks.empty()) HIP_OK(hipMemcpyAsync(dp.tasks, G.tasks.data(), G.tasks.size() * sizeof(Task), hipMemcpyHostToDevice, st));
+    if (!G.seg.empty()) HIP_OK(hipMemcpyAsync(dp.seg, G.seg.data(), G.seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+}
+
+} // namespace
+
+// ---- the factorisation object ------------------------------------------------------------------------------------------
+struct DeviceHLU {
+    Plan *plan = nullptr;
+    int device = 0, n = 0, asked = 1;
+    bool whole = true;
+    hipStream_t stream = nullptr;
+    const int *perm = nullptr; // the operator's permutation (device; owned by the operator)
+    double *factor = nullptr, *diag = nullptr;
+    Leaf *leaves = nullptr;
+    Diag *diags = nullptr;
+    int *rank = nullptr;
+    double *norm0 = nullptr, *norm2 = nullptr;
+    long long *counters = nullptr;
+    DevProgram solve_n, solve_t;
+    int64_t stats[16] = {0};
+    double seconds[4] = {0, 0, 0, 0}; // plan, unpack, factorisation, total
+    ~DeviceHLU() {
+        (void)hipSetDevice(device);
+        for (void *p : {(void *)factor, (void *)diag, (void *)leaves, (void *)diags, (void *)rank, (void *)norm0, (void *)norm2, (void *)counters, (void *)solve_n.tasks, (void *)solve_n.seg,
+                        (void *)solve_t.tasks, (void *)solve_t.seg})
+            if (p) (void)hipFree(p);
+        delete plan;
+    }
+    Ctx ctx(double *scratch, double *rhs, long long ld, int nrhs) const {
+        Ctx c;
+        c.space[SP_FACTOR] = factor; c.space[SP_DIAG] = diag; c.space[SP_SCRATCH] = scratch; c.space[SP_RHS] = rhs;
+        c.ld_rhs = ld; c.nrhs = nrhs; c.leaves = leaves; c.diags = diags; c.rank = rank; c.norm0 = norm0; c.norm2 = norm2;
+        c.eps = plan->params.eps; c.counters = counters;
+        return c;
+    }
+};
+
+void device_hlu_free(DeviceHLU *f) { delete f; }
+int device_hlu_kind(const DeviceHLU *f) { return f ? f->asked : 0; }
+
+namespace {
+
+// device tables of a plan; the factor arena is allocated but not filled
+void hlu_allocate(DeviceHLU &f) {
+    const Plan &P = *f.plan;
+    HIP_OK(hipMalloc((void **)&f.factor, std::max<size_t>((size_t)P.factor_elems * 8, 16)));
+    HIP_OK(hipMalloc((void **)&f.diag, std::max<size_t>((size_t)P.diag_elems * 8, 16)));
+    HIP_OK(hipMalloc((void **)&f.leaves, std::max<size_t>(P.leaves.size() * sizeof(Leaf), 16)));
+    HIP_OK(hipMalloc((void **)&f.diags, std::max<size_t>(P.diags.size() * sizeof(Diag), 16)));
+    HIP_OK(hipMalloc((void **)&f.rank, std::max<size_t>((size_t)P.n_slots * 4, 16)));
+    HIP_OK(hipMalloc((void **)&f.norm0, std::max<size_t>(P.leaves.size() * 8, 16)));
+    HIP_OK(hipMalloc((void **)&f.norm2, std::max<size_t>(P.leaves.size() * 8, 16)));
+    HIP_OK(hipMalloc((void **)&f.counters, 8 * sizeof(long long)));
+    HIP_OK(hipMemcpy(f.leaves, P.leaves.data(), P.leaves.size() * sizeof(Leaf), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f.diags, P.diags.data(), P.diags.size() * sizeof(Diag), hipMemcpyHostToDevice));
+    std::vector<int> r0((size_t)std::max<int64_t>(P.n_slots, 1), 0);
+    for (size_t i = 0; i < P.leaves.size(); i++) r0[i] = std::max(P.leaves[i].rank0, 0);
+    HIP_OK(hipMemcpy(f.rank, r0.data(), (size_t)P.n_slots * 4, hipMemcpyHostToDevice));
+    std::vector<double> minus(P.leaves.size(), -1.0);
+    HIP_OK(hipMemcpy(f.norm0, minus.data(), minus.size() * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(f.norm2, 0, std::max<size_t>(P.leaves.size() * 8, 16)));
+    HIP_OK(hipMemset(f.counters, 0, 8 * sizeof(long long)));
+}
+
+// windows [first, last] of the factorisation on the stream; the tasks of a window are uploaded while the previous one runs
+void hlu_run_windows(DeviceHLU &f, int first, int last, hipStream_t st) {
+    const Plan &P = *f.plan;
+    size_t max_tasks = 1, max_seg = 1;
+    for (int w = first; w <= last; w++) { max_tasks = std::max(max_tasks, P.factor[(size_t)w].tasks.size()); max_seg = std::max(max_seg, P.factor[(size_t)w].seg.size()); }
+    DevBuf tasks[2], seg[2], scratch;
+    for (int q = 0; q < 2; q++) { tasks[q].alloc(max_tasks * sizeof(Task)); seg[q].alloc(max_seg * sizeof(int64_t)); }
+    scratch.alloc((size_t)P.scratch_elems * 8);
+    const Ctx c = f.ctx(scratch.as<double>(), nullptr, 0, 0);
+    hipStream_t up = nullptr;
+    HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    hipEvent_t uploaded[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    try {
+        for (int q = 0; q < 2; q++) { HIP_OK(hipEventCreateWithFlags(&uploaded[q], hipEventDisableTiming)); HIP_OK(hipEventCreateWithFlags(&done[q], hipEventDisableTiming)); }
+        DevProgram dp[2];
+        upload_program(P.factor[(size_t)first], tasks[0], seg[0], dp[0], up);
+        HIP_OK(hipEventRecord(uploaded[0], up));
+        for (int w = first; w <= last; w++) {
+            const int q = (w - first) & 1;
+            if (w + 1 <= last) { // the other buffer is free once the window before this one has run
+                if (w > first) HIP_OK(hipStreamWaitEvent(up, done[q ^ 1], 0));
+                upload_program(P.factor[(size_t)w + 1], tasks[q ^ 1], seg[q ^ 1], dp[q ^ 1], up);
+                HIP_OK(hipEventRecord(uploaded[q ^ 1], up));
+            }
+            HIP_OK(hipStreamWaitEvent(st, uploaded[q], 0));
+            run_program(P.factor[(size_t)w], dp[q], c, P.leaves, st);
+            HIP_OK(hipEventRecord(done[q], st));
+        }
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipStreamSynchronize(up));
+    } catch (...) {
+        (void)hipDeviceSynchronize();
+        for (int q = 0; q < 2; q++) { if (uploaded[q]) (void)hipEventDestroy(uploaded[q]); if (done[q]) (void)hipEventDestroy(done[q]); }
+        (void)hipStreamDestroy(up);
+        throw;
+    }
+    for (int q = 0; q < 2; q++) { (void)hipEventDestroy(uploaded[q]); (void)hipEventDestroy(done[q]); }
+    (void)hipStreamDestroy(up);
+}
+
+void hlu_upload_solves(DeviceHLU &f) {
+    const Plan &P = *f.plan;
+    for (int pass = 0; pass < 2; pass++) {
+        const Program &G = pass ? P.solve_t : P.solve_n;
+        DevProgram &dp = pass ? f.solve_t : f.solve_n;
+        HIP_OK(hipMalloc((void **)&dp.tasks, std::max<size_t>(G.tasks.size() * sizeof(Task), 16)));
+        HIP_OK(hipMalloc((void **)&dp.seg, std::max<size_t>(G.seg.size() * sizeof(int64_t), 16)));
+        dp.n_tasks = G.tasks.size(); dp.n_seg = G.seg.size();
+        if (!G.tasks.empty()) HIP_OK(hipMemcpy(dp.tasks, G.tasks.data(), G.tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
+        if (!G.seg.empty()) HIP_OK(hipMemcpy(dp.seg, G.seg.data(), G.seg.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+}
+
+} // namespace
+
+// B (n x mu, column c at B_dev + c * ldb, CLUSTER numbering) <- A^-1 B or A^-T B, enqueued on `stream`
+void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb, int mu, void *stream) {
+    HM_CHECK(f != nullptr, "factor solve: no factorisation");
+    HM_CHECK(trans == 'N' || trans == 'T' || trans == 'C', "factor solve: trans must be 'N', 'T' or 'C'");
+    HM_CHECK(ldb >= f->n && mu >= 0, "factor solve: bad leading dimension");
+    if (f->n == 0 || mu == 0) return;
+    HIP_OK(hipSetDevice(f->device));
+    const Ctx c = f->ctx(nullptr, (double *)B_dev, ldb, mu);
+    run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, stream ? (hipStream_t)stream : f->stream);
+}
+
+// ---- diagnostic entry: a plan executed by the device kernels on HOST arrays (uploaded, run, downloaded) -----------------------
+// The counterpart of oracle/hlu_exec.cpp's hluo_run: tests feed both the same arrays, window by window, and compare.
+extern "C" int htool_hlu_debug_execute(const htool_hlu_plan *plan_, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,
+                                       int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs);
+extern "C" int htool_hlu_debug_execute(const htool_hlu_plan *plan_, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,
+                                       int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs) {
+    API_BEGIN
+    HM_CHECK(plan_ && plan_->plan, "htool_hlu_debug_execute: null plan");
+    HM_CHECK(device_count() > 0, "no HIP device available for the hierarchical LU");
+    Plan *P = plan_->plan;
+    DeviceHLU f;
+    f.plan = P;
+    struct Unown { DeviceHLU &f; ~Unown() { f.plan = nullptr; } } unown{f}; // (the plan belongs to the caller)
+    HIP_OK(hipGetDevice(&f.device));
+    f.n = P->n;
+    hlu_allocate(f);
+    const size_t nl = P->leaves.size();
+    HIP_OK(hipMemcpy(f.factor, factor, (size_t)P->factor_elems * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f.diag, diag, (size_t)P->diag_elems * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f.rank, rank, (size_t)P->n_slots * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f.norm0, norm0, nl * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f.norm2, norm2, nl * 8, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(f.counters, counters, 8 * sizeof(long long), hipMemcpyHostToDevice));
+    hipStream_t st = nullptr;
+    HIP_OK(hipStreamCreate(&st));
+    try {
+        if (first >= 0) {
+            HM_CHECK(last < (int)P->factor.size() && first <= last, "htool_hlu_debug_execute: no such window");
+            hlu_run_windows(f, first, last, st);
+        } else {
+            HM_CHECK(rhs != nullptr && ld_rhs >= P->n, "htool_hlu_debug_execute: a solve needs right-hand sides");
+            hlu_upload_solves(f);
+            DevBuf b;
+            b.alloc((size_t)ld_rhs * nrhs * 8);
+            HIP_OK(hipMemcpy(b.p, rhs, (size_t)ld_rhs * nrhs * 8, hipMemcpyHostToDevice));
+            f.stream = st;
+            device_hlu_solve(&f, first == -1 ? 'N' : 'T', b.p, ld_rhs, nrhs, st);
+            HIP_OK(hipStreamSynchronize(st));
+            HIP_OK(hipMemcpy(rhs, b.p, (size_t)ld_rhs * nrhs * 8, hipMemcpyDeviceToHost));
+        }
+        HIP_OK(hipStreamSynchronize(st));
+    } catch (...) {
+        (void)hipDeviceSynchronize();
+        (void)hipStreamDestroy(st);
+        throw;
+    }
+    (void)hipStreamDestroy(st);
+    HIP_OK(hipMemcpy(factor, f.factor, (size_t)P->factor_elems * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(diag, f.diag, (size_t)P->diag_elems * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(rank, f.rank, (size_t)P->n_slots * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(norm0, f.norm0, nl * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(norm2, f.norm2, nl * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(counters, f.counters, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    API_END
+}
+
+// library warm-up (device.hip: device_warm_up): the first launch of a kernel of this translation unit loads its code object
+namespace hm {
+__global__ void warm_kernel_hlu() {}
+void warm_up_hlu() { hipLaunchKernelGGL(warm_kernel_hlu, dim3(1), dim3(64), 0, 0); }
+} // namespace hm

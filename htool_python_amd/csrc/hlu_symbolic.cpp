@@ -1,0 +1,683 @@
+// hlu_symbolic.cpp -- the plan of a hierarchical LU: block tree from the leaves, the block-recursive algorithm run on the
+// structure alone, leaf-level tasks with dependency levels (see hlu.hpp).  Host code, no numbers are touched here.
+//
+// Reference surface: htool::lu_factorization / lu_solve (bound at src/htool/hmatrix/hmatrix.hpp:58-78), cholesky_* (:61-94).
+#include "hlu.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <deque>
+#include <unordered_map>
+
+#include "common.hpp"
+
+namespace hm {
+namespace hlu {
+
+namespace {
+
+// Dependency state of one buffer whose rows are grouped by cluster-leaf cell (or of a dense leaf: one cell).
+struct Track {
+    int c0 = 0, nc = 1;
+    int base_w = 0, base_r = 0, acc = 0, maxw = 0, maxr = 0;
+    std::vector<int> w, r; // per cell, created by the first per-cell access
+    void init(int c0_, int nc_) { c0 = c0_; nc = nc_; }
+    int dep_read(int a, int b) const {
+        int L = std::max(base_w, acc);
+        if (!w.empty()) for (int c = a; c < b; c++) L = std::max(L, w[c - c0]);
+        return L;
+    }
+    void note_read(int a, int b, int lev) {
+        if (r.empty()) r.assign(nc, 0);
+        for (int c = a; c < b; c++) r[c - c0] = std::max(r[c - c0], lev);
+        maxr = std::max(maxr, lev);
+    }
+    int dep_write(int a, int b) const {
+        int L = std::max(std::max(base_w, base_r), acc);
+        if (!w.empty()) for (int c = a; c < b; c++) L = std::max(L, w[c - c0]);
+        if (!r.empty()) for (int c = a; c < b; c++) L = std::max(L, r[c - c0]);
+        return L;
+    }
+    void note_write(int a, int b, int lev) {
+        if (w.empty()) w.assign(nc, 0);
+        for (int c = a; c < b; c++) w[c - c0] = lev;
+        maxw = std::max(maxw, lev);
+    }
+    int dep_read_all() const { return std::max(std::max(base_w, acc), maxw); }
+    void note_read_all(int lev) { base_r = std::max(base_r, lev); maxr = std::max(maxr, lev); }
+    int dep_write_all() const { return std::max(std::max(std::max(base_w, base_r), acc), std::max(maxw, maxr)); }
+    void note_write_all(int lev) { base_w = lev; maxw = std::max(maxw, lev); }
+    int dep_acc() const { return std::max(std::max(base_w, base_r), std::max(maxw, maxr)); }
+    void note_acc(int lev) { acc = std::max(acc, lev); }
+};
+
+struct BNode {
+    int t, s;
+    int kids;  // first entry in the kid table (nct x ncs entries, -1: empty block), -1 for a leaf
+    int split; // bit 0: the target node is split, bit 1: the source node
+    int leaf;  // leaf id, or -1
+};
+
+// a thin block of columns whose rows are cluster positions [pos0, ...)
+struct Thin {
+    int64_t base = 0;
+    int ld = 0, pos0 = 0, space = SP_FACTOR;
+    Track *tr = nullptr; // per-cell dependency state, or
+    int opleaf = -1;     // a finished leaf read as a whole
+    bool transposed = false; // element (row, col) at base + row * ld + col (a dense leaf seen as its transpose)
+};
+
+struct Emitter {
+    const ClusterTree &T;
+    Plan &P;
+    std::vector<BNode> bn;
+    std::vector<int> kid;
+    std::vector<int> diag_bnode, cell0, cell1;
+    std::vector<Track> trU, trV, trD;
+    std::vector<char> dirty;
+    std::deque<Track> temp_tracks; // scratch buffers of the group being emitted
+    std::vector<Task> cur;
+    int window_base = 1, max_level = 0;
+    int64_t scratch_used = 0;
+    int64_t next_slot = 0;
+    bool planning_factor = true;
+
+    Emitter(const ClusterTree &T_, Plan &P_) : T(T_), P(P_) {}
+
+    int end(int x) const { return T.offset[x] + T.size[x]; }
+    bool overlap(int x, int y) const { return T.offset[x] < end(y) && T.offset[y] < end(x); }
+    int smaller(int x, int y) const { return T.size[x] <= T.size[y] ? x : y; }
+    int child_containing(int parent, int x) const {
+        for (int a = 0; a < T.n_child[parent]; a++) {
+            const int c = T.first_child[parent] + a;
+            if (T.offset[x] >= T.offset[c] && end(x) <= end(c) && T.size[c] > 0) return a;
+        }
+        throw Error("hierarchical LU: inconsistent cluster tree");
+    }
+
+    // ---- block tree from the leaves: the split rule of blocktree.cpp, a leaf wherever the operator has one ----
+    int build_bnode(int t, int s, const std::unordered_map<uint64_t, int> &leaf_of) {
+        const int id = (int)bn.size();
+        bn.push_back({t, s, -1, 0, -1});
+        if (t == s) diag_bnode[t] = id;
+        auto it = leaf_of.find(((uint64_t)(uint32_t)t << 32) | (uint32_t)s);
+        if (it != leaf_of.end()) { bn[id].leaf = it->second; return id; }
+        const bool lt = T.is_leaf(t), ls = T.is_leaf(s);
+        HM_CHECK(!(lt && ls), "hierarchical LU: the leaves do not tile the operator (a pair of cluster leaves without a leaf)");
+        int split;
+        if (ls || (!lt && T.size[t] > T.size[s])) split = 1;
+        else if (lt || T.size[s] > T.size[t]) split = 2;
+        else split = 3;
+        const int nct = (split & 1) ? T.n_child[t] : 1, ncs = (split & 2) ? T.n_child[s] : 1;
+        const int k0 = (int)kid.size();
+        kid.resize(kid.size() + (size_t)nct * ncs, -1);
+        bn[id].kids = k0;
+        bn[id].split = split;
+        for (int a = 0; a < nct; a++)
+            for (int b = 0; b < ncs; b++) {
+                const int ct = (split & 1) ? T.first_child[t] + a : t, cs = (split & 2) ? T.first_child[s] + b : s;
+                if (T.size[ct] == 0 || T.size[cs] == 0) continue;
+                const int c = build_bnode(ct, cs, leaf_of);
+                kid[k0 + a * ncs + b] = c;
+            }
+        return id;
+    }
+    int ncs_of(const BNode &B) const { return (B.split & 2) ? T.n_child[B.s] : 1; }
+    int nct_of(const BNode &B) const { return (B.split & 1) ? T.n_child[B.t] : 1; }
+
+    // deepest block node that covers (t, s), starting from a node that does
+    int descend(int b, int t, int s) const {
+        for (;;) {
+            const BNode &B = bn[b];
+            if (B.leaf >= 0) return b;
+            int ti = 0, si = 0;
+            if (B.split & 1) { if (t == B.t) return b; ti = child_containing(B.t, t); }
+            if (B.split & 2) { if (s == B.s) return b; si = child_containing(B.s, s); }
+            const int c = kid[B.kids + ti * ncs_of(B) + si];
+            HM_CHECK(c >= 0, "hierarchical LU: empty block");
+            b = c;
+        }
+    }
+    template <typename F>
+    void for_leaves(int b, int t, int s, F &&f) const { // leaves below b that meet (t, s), with the intersection
+        const BNode &B = bn[b];
+        if (B.leaf >= 0) { f(B.leaf, smaller(t, B.t), smaller(s, B.s)); return; }
+        const int n = nct_of(B) * ncs_of(B);
+        for (int q = 0; q < n; q++) {
+            const int c = kid[B.kids + q];
+            if (c >= 0 && overlap(bn[c].t, t) && overlap(bn[c].s, s)) for_leaves(c, t, s, f);
+        }
+    }
+
+    // ---- tasks ----
+    int emit(Task &tk, int dep) {
+        tk.level = std::max(dep + 1, window_base);
+        max_level = std::max(max_level, tk.level);
+        cur.push_back(tk);
+        P.counts[tk.type]++;
+        return tk.level;
+    }
+    static Task blank(int type) {
+        Task t;
+        t.type = type; t.flags = 0; t.level = 0; t.leaf = -1; t.kref = -1; t.kconst = 0; t.m = t.n = t.r0 = t.c0 = 0;
+        t.a_ld = t.b_ld = t.x_ld = t.y_ld = 0; t.a = t.b = t.x = t.y = t.w = 0;
+        return t;
+    }
+    int64_t ref(const Thin &X, int pos) const { return make_ref(X.space, X.base + (X.transposed ? (int64_t)(pos - X.pos0) * X.ld : (int64_t)(pos - X.pos0))); }
+    int dep_leaf_read(int l) const { return std::max(trU[l].dep_read_all(), trV[l].dep_read_all()); }
+    void note_leaf_read(int l, int lev) { trU[l].note_read_all(lev); trV[l].note_read_all(lev); }
+    int dep_thin_read(const Thin &X, int node) const { return X.opleaf >= 0 ? dep_leaf_read(X.opleaf) : X.tr->dep_read(cell0[node], cell1[node]); }
+    void note_thin_read(const Thin &X, int node, int lev) { if (X.opleaf >= 0) note_leaf_read(X.opleaf, lev); else X.tr->note_read(cell0[node], cell1[node], lev); }
+
+    void ensure_final(int l) {
+        if (!dirty[l]) return;
+        Task t = blank(T_FINAL);
+        t.leaf = l;
+        const int lev = emit(t, std::max(trU[l].dep_write_all(), trV[l].dep_write_all()));
+        trU[l].note_write_all(lev);
+        trV[l].note_write_all(lev);
+        dirty[l] = 0;
+    }
+    Thin leaf_u(int l) { const Leaf &L = P.leaves[l]; Thin X; X.base = L.u; X.ld = L.m; X.pos0 = L.t_off; X.space = SP_FACTOR; X.opleaf = l; return X; }
+    Thin leaf_v(int l) { const Leaf &L = P.leaves[l]; Thin X; X.base = L.v; X.ld = L.n; X.pos0 = L.s_off; X.space = SP_FACTOR; X.opleaf = l; return X; }
+    void begin_group() { maybe_close_window(); temp_tracks.clear(); } // the scratch blocks of a group are referenced by its own tasks only
+    Thin new_scratch(int node, int cols) {
+        Thin X;
+        X.base = scratch_used;
+        X.ld = T.size[node];
+        X.pos0 = T.offset[node];
+        X.space = SP_SCRATCH;
+        scratch_used += ((int64_t)T.size[node] * cols + 1) & ~(int64_t)1;
+        temp_tracks.emplace_back();
+        temp_tracks.back().init(cell0[node], cell1[node] - cell0[node]);
+        X.tr = &temp_tracks.back();
+        return X;
+    }
+    void fill_zero(const Thin &Y, int node, int kref, int kconst) {
+        Task t = blank(T_FILL);
+        t.m = T.size[node];
+        t.kref = kref; t.kconst = kconst;
+        t.y = ref(Y, T.offset[node]);
+        t.y_ld = Y.ld;
+        const int lev = emit(t, Y.tr->dep_write(cell0[node], cell1[node]));
+        Y.tr->note_write(cell0[node], cell1[node], lev);
+    }
+    // Y[rows of the output side] (+)= -+ op(leaf restricted to (it, is)) X[rows of the input side]
+    void apply_leaf(int l, int it, int is, bool trans, const Thin &X, const Thin &Y, int kref, int kconst, bool accum, bool sub) {
+        const Leaf &L = P.leaves[l];
+        if (L.kind == 1) ensure_final(l);
+        const int in = trans ? it : is, out = trans ? is : it;
+        Task t = blank(L.kind == 1 ? T_APPLY_LR : T_APPLY_DENSE);
+        t.leaf = l;
+        t.flags = (trans ? F_TRANS : 0) | (accum ? F_ACCUM : 0) | (sub ? F_SUB : 0);
+        t.kref = kref; t.kconst = kconst;
+        t.m = T.size[out];
+        t.n = T.size[in];
+        if (L.kind == 1) {
+            const int64_t urow = L.u + (T.offset[it] - L.t_off), vrow = L.v + (T.offset[is] - L.s_off);
+            t.a = make_ref(SP_FACTOR, trans ? vrow : urow); t.a_ld = trans ? L.n : L.m;
+            t.b = make_ref(SP_FACTOR, trans ? urow : vrow); t.b_ld = trans ? L.m : L.n;
+        } else {
+            HM_CHECK(it == bn_t(l) && is == bn_s(l), "hierarchical LU: a dense leaf cannot be restricted");
+            t.a = make_ref(SP_FACTOR, L.u); t.a_ld = L.m;
+        }
+        t.x = ref(X, T.offset[in]); t.x_ld = X.ld;
+        t.y = ref(Y, T.offset[out]); t.y_ld = Y.ld;
+        int dep = std::max(dep_leaf_read(l), dep_thin_read(X, in));
+        dep = std::max(dep, Y.tr->dep_write(cell0[out], cell1[out]));
+        const int lev = emit(t, dep);
+        note_leaf_read(l, lev);
+        note_thin_read(X, in, lev);
+        Y.tr->note_write(cell0[out], cell1[out], lev);
+    }
+    int bn_t(int l) const { return leaf_t[l]; }
+    int bn_s(int l) const { return leaf_s[l]; }
+    std::vector<int> leaf_t, leaf_s;
+
+    // X[rows of t] <- op(inverse factor of the diagonal leaf of t) X[rows of t]
+    void apply_diag(int t, int which, bool trans, const Thin &X, int kref, int kconst) {
+        const int l = bn[diag_bnode[t]].leaf;
+        const Diag &D = P.diags[P.leaves[l].diag];
+        Task tk = blank(T_APPLY_DENSE);
+        tk.leaf = l;
+        tk.flags = F_INPLACE | (trans ? F_TRANS : 0);
+        tk.kref = kref; tk.kconst = kconst;
+        tk.m = tk.n = D.m;
+        tk.a = make_ref(SP_DIAG, which ? D.uinv : D.linv); tk.a_ld = D.m;
+        tk.x = tk.y = ref(X, T.offset[t]); tk.x_ld = tk.y_ld = X.ld;
+        const int dep = std::max(trD[P.leaves[l].diag].dep_read_all(), X.tr->dep_write(cell0[t], cell1[t]));
+        const int lev = emit(tk, dep);
+        trD[P.leaves[l].diag].note_read_all(lev);
+        X.tr->note_write(cell0[t], cell1[t], lev);
+    }
+    // target leaf lc, sub-block (it, is):  -= X[rows of it] Z[rows of is]^T
+    void add_lr(int lc, int it, int is, const Thin &X, const Thin &Z, int kref, int kconst) {
+        const Leaf &L = P.leaves[lc];
+        Task t = blank(T_ADDLR);
+        t.leaf = lc;
+        t.flags = F_SUB | (X.transposed ? F_XT : 0) | (Z.transposed ? F_YT : 0);
+        t.kref = kref; t.kconst = kconst;
+        t.m = T.size[it]; t.n = T.size[is];
+        t.r0 = T.offset[it] - L.t_off; t.c0 = T.offset[is] - L.s_off;
+        t.x = ref(X, T.offset[it]); t.x_ld = X.ld;
+        t.y = ref(Z, T.offset[is]); t.y_ld = Z.ld;
+        int dep = std::max(dep_thin_read(X, it), dep_thin_read(Z, is));
+        dep = std::max(dep, L.kind == 1 ? std::max(trU[lc].dep_acc(), trV[lc].dep_acc()) : trU[lc].dep_acc());
+        const int lev = emit(t, dep);
+        note_thin_read(X, it, lev);
+        note_thin_read(Z, is, lev);
+        trU[lc].note_acc(lev);
+        if (L.kind == 1) { trV[lc].note_acc(lev); dirty[lc] = 1; }
+    }
+
+    void maybe_close_window() {
+        if (scratch_used > P.params.window_scratch_elems || (int64_t)cur.size() > P.params.window_tasks) close_window();
+    }
+    void close_window() {
+        if (cur.empty()) return;
+        P.factor.emplace_back();
+        finish_program(cur, P.factor.back());
+        P.factor.back().scratch_elems = scratch_used;
+        P.scratch_elems = std::max(P.scratch_elems, scratch_used);
+        scratch_used = 0;
+        window_base = max_level + 1;
+        temp_tracks.clear();
+    }
+    void finish_program(std::vector<Task> &tasks, Program &out) {
+        // stable counting sort by (level, type); runs of one target inside the ADDLR / FINAL buckets
+        int lo = INT32_MAX, hi = 0;
+        for (const Task &t : tasks) { lo = std::min(lo, t.level); hi = std::max(hi, t.level); }
+        if (tasks.empty()) { lo = 1; hi = 0; }
+        const int64_t nkeys = (int64_t)(hi - lo + 1) * T_NTYPES;
+        std::vector<int64_t> start((size_t)nkeys + 1, 0);
+        for (const Task &t : tasks) start[(size_t)(t.level - lo) * T_NTYPES + t.type + 1]++;
+        for (int64_t k = 0; k < nkeys; k++) start[k + 1] += start[k];
+        out.tasks.resize(tasks.size());
+        {
+            std::vector<int64_t> pos(start.begin(), start.end() - 1);
+            for (const Task &t : tasks) out.tasks[pos[(size_t)(t.level - lo) * T_NTYPES + t.type]++] = t;
+        }
+        tasks.clear();
+        tasks.shrink_to_fit();
+        for (int64_t k = 0; k < nkeys; k++) {
+            if (start[k + 1] == start[k]) continue;
+            Bucket b;
+            b.type = (int)(k % T_NTYPES); b.level = lo + (int)(k / T_NTYPES);
+            b.begin = start[k]; b.end = start[k + 1];
+            b.seg_begin = b.seg_end = 0;
+            if (b.type == T_ADDLR || b.type == T_FINAL) {
+                std::stable_sort(out.tasks.begin() + b.begin, out.tasks.begin() + b.end, [](const Task &x, const Task &y) { return x.leaf < y.leaf; });
+                b.seg_begin = (int64_t)out.seg.size();
+                for (int64_t i = b.begin; i < b.end; i++)
+                    if (i == b.begin || out.tasks[i].leaf != out.tasks[i - 1].leaf) out.seg.push_back(i);
+                b.seg_end = (int64_t)out.seg.size();
+                out.seg.push_back(b.end); // end marker of the last run
+            }
+            out.buckets.push_back(b);
+        }
+        out.n_levels = out.tasks.empty() ? 0 : hi - lo + 1;
+    }
+
+    // ---- the products C(t, s) -= A(t, r) B(r, s) ----
+    void mm(int t, int r, int s, int a, int b, int c) {
+        if (T.size[t] == 0 || T.size[r] == 0 || T.size[s] == 0) return;
+        a = descend(a, t, r);
+        b = descend(b, r, s);
+        c = descend(c, t, s);
+        const BNode &A = bn[a], &B = bn[b];
+        const bool a_lr = A.leaf >= 0 && P.leaves[A.leaf].kind == 1, b_lr = B.leaf >= 0 && P.leaves[B.leaf].kind == 1;
+        if (a_lr) { // (U_a V_a^T) B = U_a (B^T V_a)^T
+            begin_group();
+            const int la = A.leaf;
+            ensure_final(la);
+            Thin Z = new_scratch(s, P.leaves[la].cap);
+            fill_zero(Z, s, la, 0);
+            const Thin Va = leaf_v(la), Ua = leaf_u(la);
+            for_leaves(b, r, s, [&](int l, int it, int is) { apply_leaf(l, it, is, true, Va, Z, la, 0, true, false); });
+            for_leaves(c, t, s, [&](int l, int it, int is) { add_lr(l, it, is, Ua, Z, la, 0); });
+            return;
+        }
+        if (b_lr) { // A (U_b V_b^T) = (A U_b) V_b^T
+            begin_group();
+            const int lb = B.leaf;
+            ensure_final(lb);
+            Thin X = new_scratch(t, P.leaves[lb].cap);
+            fill_zero(X, t, lb, 0);
+            const Thin Ub = leaf_u(lb), Vb = leaf_v(lb);
+            for_leaves(a, t, r, [&](int l, int it, int is) { apply_leaf(l, it, is, false, Ub, X, lb, 0, true, false); });
+            for_leaves(c, t, s, [&](int l, int it, int is) { add_lr(l, it, is, X, Vb, lb, 0); });
+            return;
+        }
+        if (A.leaf >= 0 && B.leaf >= 0) { // two dense leaves: t, r, s are cluster leaves
+            begin_group();
+            const Leaf &LA = P.leaves[A.leaf], &LB = P.leaves[B.leaf];
+            const BNode &C = bn[c];
+            HM_CHECK(C.leaf >= 0, "hierarchical LU: the target of a product of dense leaves is not a leaf");
+            Thin Da = leaf_u(A.leaf);
+            if (P.leaves[C.leaf].kind == 0) {
+                Thin Dbt = leaf_u(B.leaf); // D_b^T: rows = columns of D_b
+                Dbt.transposed = true; Dbt.ld = LB.m; Dbt.pos0 = LB.s_off;
+                add_lr(C.leaf, t, s, Da, Dbt, -1, LA.n);
+                return;
+            }
+            const int kp = std::min(LA.m, LB.n);
+            Thin X = new_scratch(t, kp), Z = new_scratch(s, kp);
+            const int64_t w = scratch_used;
+            scratch_used += ((int64_t)LA.m * LB.n + 1) & ~(int64_t)1;
+            Task tk = blank(T_DDPROD);
+            tk.leaf = C.leaf;
+            tk.kref = (int)next_slot++;
+            tk.kconst = kp;
+            tk.m = LA.m; tk.n = LB.n; tk.r0 = LA.n;
+            tk.a = make_ref(SP_FACTOR, LA.u); tk.a_ld = LA.m;
+            tk.b = make_ref(SP_FACTOR, LB.u); tk.b_ld = LB.m;
+            tk.x = ref(X, T.offset[t]); tk.x_ld = X.ld;
+            tk.y = ref(Z, T.offset[s]); tk.y_ld = Z.ld;
+            tk.w = make_ref(SP_SCRATCH, w);
+            const int lev = emit(tk, std::max(dep_leaf_read(A.leaf), dep_leaf_read(B.leaf)));
+            note_leaf_read(A.leaf, lev);
+            note_leaf_read(B.leaf, lev);
+            X.tr->note_write(cell0[t], cell1[t], lev);
+            Z.tr->note_write(cell0[s], cell1[s], lev);
+            add_lr(C.leaf, t, s, X, Z, tk.kref, 0);
+            return;
+        }
+        // a covering node that cannot descend any more is split exactly where (t, r) / (r, s) touches its own clusters
+        const bool st = A.leaf < 0 && (A.split & 1) && t == A.t;
+        const bool sr = (A.leaf < 0 && (A.split & 2) && r == A.s) || (B.leaf < 0 && (B.split & 1) && r == B.t);
+        const bool ss = B.leaf < 0 && (B.split & 2) && s == B.s;
+        HM_CHECK(st || sr || ss, "hierarchical LU: the product recursion cannot descend");
+        HM_CHECK((!st || T.n_child[t] > 0) && (!sr || T.n_child[r] > 0) && (!ss || T.n_child[s] > 0), "hierarchical LU: split of a cluster leaf");
+        const int nt = st ? T.n_child[t] : 1, nr = sr ? T.n_child[r] : 1, ns = ss ? T.n_child[s] : 1;
+        for (int i = 0; i < nt; i++)
+            for (int k = 0; k < nr; k++)
+                for (int j = 0; j < ns; j++)
+                    mm(st ? T.first_child[t] + i : t, sr ? T.first_child[r] + k : r, ss ? T.first_child[s] + j : s, a, b, c);
+    }
+    int block_of(int t, int s) const { // block node of two children of one cluster node
+        const BNode &D = bn[diag_bnode[T.parent[t]]];
+        const int c = kid[D.kids + (t - T.first_child[T.parent[t]]) * T.n_child[T.parent[t]] + (s - T.first_child[T.parent[t]])];
+        HM_CHECK(c >= 0, "hierarchical LU: empty off-diagonal block");
+        return c;
+    }
+
+    // X[rows of t] <- L(t,t)^-1 X[rows of t]   (forward substitution through the leaves of L)
+    void thin_solve_l(int t, const Thin &X, int kref, int kconst) {
+        if (T.size[t] == 0) return;
+        if (bn[diag_bnode[t]].leaf >= 0) { apply_diag(t, 0, false, X, kref, kconst); return; }
+        const int nc = T.n_child[t], f = T.first_child[t];
+        for (int i = 0; i < nc; i++) {
+            if (T.size[f + i] == 0) continue;
+            thin_solve_l(f + i, X, kref, kconst);
+            for (int j = i + 1; j < nc; j++) {
+                if (T.size[f + j] == 0) continue;
+                for_leaves(block_of(f + j, f + i), f + j, f + i, [&](int l, int it, int is) { apply_leaf(l, it, is, false, X, X, kref, kconst, true, true); });
+            }
+        }
+    }
+    // X[rows of s] <- U(s,s)^-T X[rows of s]   (forward substitution with the transposed upper factor)
+    void thin_solve_ut(int s, const Thin &X, int kref, int kconst) {
+        if (T.size[s] == 0) return;
+        if (bn[diag_bnode[s]].leaf >= 0) { apply_diag(s, 1, true, X, kref, kconst); return; }
+        const int nc = T.n_child[s], f = T.first_child[s];
+        for (int i = 0; i < nc; i++) {
+            if (T.size[f + i] == 0) continue;
+            thin_solve_ut(f + i, X, kref, kconst);
+            for (int j = i + 1; j < nc; j++) {
+                if (T.size[f + j] == 0) continue;
+                for_leaves(block_of(f + i, f + j), f + i, f + j, [&](int l, int it, int is) { apply_leaf(l, it, is, true, X, X, kref, kconst, true, true); });
+            }
+        }
+    }
+    // X[rows of t] <- U(t,t)^-1 X[rows of t]   (backward substitution)
+    void thin_solve_u(int t, const Thin &X, int kref, int kconst) {
+        if (T.size[t] == 0) return;
+        if (bn[diag_bnode[t]].leaf >= 0) { apply_diag(t, 1, false, X, kref, kconst); return; }
+        const int nc = T.n_child[t], f = T.first_child[t];
+        for (int i = nc - 1; i >= 0; i--) {
+            if (T.size[f + i] == 0) continue;
+            thin_solve_u(f + i, X, kref, kconst);
+            for (int j = i - 1; j >= 0; j--) {
+                if (T.size[f + j] == 0) continue;
+                for_leaves(block_of(f + j, f + i), f + j, f + i, [&](int l, int it, int is) { apply_leaf(l, it, is, false, X, X, kref, kconst, true, true); });
+            }
+        }
+    }
+    // X[rows of t] <- L(t,t)^-T X[rows of t]   (backward substitution with the transposed lower factor)
+    void thin_solve_lt(int t, const Thin &X, int kref, int kconst) {
+        if (T.size[t] == 0) return;
+        if (bn[diag_bnode[t]].leaf >= 0) { apply_diag(t, 0, true, X, kref, kconst); return; }
+        const int nc = T.n_child[t], f = T.first_child[t];
+        for (int i = nc - 1; i >= 0; i--) {
+            if (T.size[f + i] == 0) continue;
+            thin_solve_lt(f + i, X, kref, kconst);
+            for (int j = i - 1; j >= 0; j--) {
+                if (T.size[f + j] == 0) continue;
+                for_leaves(block_of(f + i, f + j), f + i, f + j, [&](int l, int it, int is) { apply_leaf(l, it, is, true, X, X, kref, kconst, true, true); });
+            }
+        }
+    }
+
+    // B(t, s) <- L(t,t)^-1 B(t, s)
+    void solve_l(int t, int s, int b) {
+        if (T.size[t] == 0 || T.size[s] == 0) return;
+        b = descend(b, t, s);
+        const BNode &B = bn[b];
+        HM_CHECK(B.t == t && B.s == s, "hierarchical LU: a triangular solve met a block that is not a node of the block tree");
+        if (B.leaf >= 0) {
+            const Leaf &L = P.leaves[B.leaf];
+            if (L.kind == 1) {
+                ensure_final(B.leaf);
+                Thin X = leaf_u(B.leaf);
+                X.opleaf = -1; X.tr = &trU[B.leaf];
+                thin_solve_l(t, X, B.leaf, 0);
+            } else {
+                Thin X = leaf_u(B.leaf);
+                X.opleaf = -1; X.tr = &trU[B.leaf];
+                apply_diag(t, 0, false, X, -1, L.n);
+            }
+            return;
+        }
+        const int ns = (B.split & 2) ? T.n_child[s] : 1;
+        for (int j = 0; j < ns; j++) {
+            const int sj = (B.split & 2) ? T.first_child[s] + j : s;
+            if (!(B.split & 1)) { solve_l(t, sj, b); continue; }
+            const int nc = T.n_child[t], f = T.first_child[t];
+            for (int i = 0; i < nc; i++) {
+                solve_l(f + i, sj, b);
+                for (int i2 = i + 1; i2 < nc; i2++) mm(f + i2, f + i, sj, diag_bnode[t], b, b);
+            }
+        }
+    }
+    // B(t, s) <- B(t, s) U(s,s)^-1
+    void solve_u(int t, int s, int b) {
+        if (T.size[t] == 0 || T.size[s] == 0) return;
+        b = descend(b, t, s);
+        const BNode &B = bn[b];
+        HM_CHECK(B.t == t && B.s == s, "hierarchical LU: a triangular solve met a block that is not a node of the block tree");
+        if (B.leaf >= 0) {
+            const Leaf &L = P.leaves[B.leaf];
+            if (L.kind == 1) {
+                ensure_final(B.leaf);
+                Thin X = leaf_v(B.leaf);
+                X.opleaf = -1; X.tr = &trV[B.leaf];
+                thin_solve_ut(s, X, B.leaf, 0);
+            } else { // D <- D U^-1: the rows of D^T, in place
+                const int ld = bn[diag_bnode[s]].leaf;
+                const Diag &D = P.diags[P.leaves[ld].diag];
+                Task tk = blank(T_APPLY_DENSE);
+                tk.leaf = ld;
+                tk.flags = F_INPLACE | F_TRANS | F_XT | F_YT;
+                tk.kref = -1; tk.kconst = L.m;
+                tk.m = tk.n = D.m;
+                tk.a = make_ref(SP_DIAG, D.uinv); tk.a_ld = D.m;
+                tk.x = tk.y = make_ref(SP_FACTOR, L.u); tk.x_ld = tk.y_ld = L.m;
+                const int dep = std::max(trD[P.leaves[ld].diag].dep_read_all(), trU[B.leaf].dep_write_all());
+                const int lev = emit(tk, dep);
+                trD[P.leaves[ld].diag].note_read_all(lev);
+                trU[B.leaf].note_write_all(lev);
+            }
+            return;
+        }
+        const int nt = (B.split & 1) ? T.n_child[t] : 1;
+        for (int i = 0; i < nt; i++) {
+            const int ti = (B.split & 1) ? T.first_child[t] + i : t;
+            if (!(B.split & 2)) { solve_u(ti, s, b); continue; }
+            const int nc = T.n_child[s], f = T.first_child[s];
+            for (int j = 0; j < nc; j++) {
+                solve_u(ti, f + j, b);
+                for (int j2 = j + 1; j2 < nc; j2++) mm(ti, f + j, f + j2, b, diag_bnode[s], b);
+            }
+        }
+    }
+    void lu(int t) {
+        if (T.size[t] == 0) return;
+        const int d = diag_bnode[t];
+        HM_CHECK(d >= 0, "hierarchical LU: a diagonal block is missing");
+        if (bn[d].leaf >= 0) {
+            const int l = bn[d].leaf;
+            const Leaf &L = P.leaves[l];
+            HM_CHECK(L.kind == 0 && L.diag >= 0, "hierarchical LU: a diagonal leaf is not dense");
+            Task tk = blank(T_GETRF);
+            tk.leaf = l;
+            tk.m = tk.n = L.m;
+            const int lev = emit(tk, std::max(trU[l].dep_write_all(), trD[L.diag].dep_write_all()));
+            trU[l].note_write_all(lev);
+            trD[L.diag].note_write_all(lev);
+            return;
+        }
+        const int nc = T.n_child[t], f = T.first_child[t];
+        for (int i = 0; i < nc; i++) {
+            if (T.size[f + i] == 0) continue;
+            lu(f + i);
+            for (int j = i + 1; j < nc; j++) {
+                solve_l(f + i, f + j, d);
+                solve_u(f + j, f + i, d);
+            }
+            for (int j = i + 1; j < nc; j++)
+                for (int k = i + 1; k < nc; k++) mm(f + j, f + i, f + k, d, d, d);
+        }
+    }
+};
+
+} // namespace
+
+Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Params &prm) {
+    const double t0 = wall_seconds();
+    HM_CHECK(prm.cap_max <= 64 && prm.cap_min >= 8 && prm.cap_min <= prm.cap_max, "hierarchical LU: leaf capacities must lie in [8, 64]");
+    std::unique_ptr<Plan> plan(new Plan);
+    Plan &P = *plan;
+    P.tree = &T;
+    P.params = prm;
+    P.n = T.n_points;
+    Emitter E(T, P);
+    const int nn = T.node_count();
+    // cells: the cluster leaves in position order
+    E.cell0.assign(nn, 0);
+    E.cell1.assign(nn, 0);
+    {
+        std::vector<int> leaves;
+        for (int v = 0; v < nn; v++) if (T.is_leaf(v) && T.size[v] > 0) leaves.push_back(v);
+        std::sort(leaves.begin(), leaves.end(), [&](int x, int y) { return T.offset[x] < T.offset[y]; });
+        for (size_t c = 0; c < leaves.size(); c++) { E.cell0[leaves[c]] = (int)c; E.cell1[leaves[c]] = (int)c + 1; }
+        for (int v = nn - 1; v >= 0; v--) { // children have larger ids than their parent
+            if (T.is_leaf(v)) continue;
+            int lo = INT32_MAX, hi = 0;
+            for (int a = 0; a < T.n_child[v]; a++) {
+                const int c = T.first_child[v] + a;
+                if (T.size[c] == 0) continue;
+                lo = std::min(lo, E.cell0[c]); hi = std::max(hi, E.cell1[c]);
+            }
+            E.cell0[v] = lo == INT32_MAX ? 0 : lo; E.cell1[v] = hi;
+        }
+    }
+    // leaves and arenas
+    std::unordered_map<uint64_t, int> leaf_of;
+    leaf_of.reserve(in.size() * 2);
+    P.leaves.resize(in.size());
+    E.leaf_t.resize(in.size());
+    E.leaf_s.resize(in.size());
+    int64_t fe = 0, de = 0;
+    for (size_t i = 0; i < in.size(); i++) {
+        const LeafIn &li = in[i];
+        HM_CHECK(li.t_node >= 0 && li.t_node < nn && li.s_node >= 0 && li.s_node < nn, "hierarchical LU: leaf with an unknown cluster node");
+        Leaf &L = P.leaves[i];
+        L.t_off = T.offset[li.t_node]; L.m = T.size[li.t_node];
+        L.s_off = T.offset[li.s_node]; L.n = T.size[li.s_node];
+        L.kind = li.rank >= 0 ? 1 : 0;
+        L.rank0 = li.rank;
+        L.diag = -1;
+        L.u = fe;
+        if (L.kind == 1) {
+            // (small leaves next to the diagonal gain the most rank from the Schur complements and cost next to nothing: they get room for half their size)
+            L.cap = std::min(prm.cap_max, std::max(std::max(prm.cap_min, std::min(32, std::min(L.m, L.n) / 2)), (int)std::ceil(prm.cap_factor * li.rank) + prm.cap_extra));
+            HM_CHECK(li.rank <= L.cap - 4, "hierarchical LU: the rank of a leaf exceeds what the low-rank arithmetic is sized for");
+            fe += ((int64_t)L.m * L.cap + 1) & ~(int64_t)1;
+            L.v = fe;
+            fe += ((int64_t)L.n * L.cap + 1) & ~(int64_t)1;
+        } else {
+            L.cap = 0;
+            L.v = 0;
+            fe += ((int64_t)L.m * L.n + 1) & ~(int64_t)1;
+            if (li.t_node == li.s_node) {
+                L.diag = (int)P.diags.size();
+                Diag D;
+                D.leaf = (int)i; D.m = L.m;
+                D.linv = de; de += (int64_t)L.m * L.m;
+                D.uinv = de; de += (int64_t)L.m * L.m;
+                P.diags.push_back(D);
+            }
+        }
+        E.leaf_t[i] = li.t_node; E.leaf_s[i] = li.s_node;
+        const bool fresh = leaf_of.emplace(((uint64_t)(uint32_t)li.t_node << 32) | (uint32_t)li.s_node, (int)i).second;
+        HM_CHECK(fresh, "hierarchical LU: a block appears twice among the leaves");
+    }
+    P.factor_elems = fe;
+    P.diag_elems = de;
+    E.next_slot = (int64_t)in.size();
+    E.diag_bnode.assign(nn, -1);
+    E.build_bnode(0, 0, leaf_of);
+    {
+        int64_t used = 0;
+        for (const BNode &b : E.bn) used += b.leaf >= 0;
+        HM_CHECK(used == (int64_t)in.size(), "hierarchical LU: leaves outside the block tree of the cluster tree (an operator built with other splitting rules)");
+    }
+    E.trU.resize(in.size());
+    E.trV.resize(in.size());
+    E.trD.resize(P.diags.size());
+    E.dirty.assign(in.size(), 0);
+    for (size_t i = 0; i < in.size(); i++) {
+        E.trU[i].init(E.cell0[in[i].t_node], E.cell1[in[i].t_node] - E.cell0[in[i].t_node]);
+        E.trV[i].init(E.cell0[in[i].s_node], E.cell1[in[i].s_node] - E.cell0[in[i].s_node]);
+    }
+    // window 0: every low-rank leaf is truncated once (ranks of the compression -> ranks of the arithmetic; norms)
+    for (size_t i = 0; i < in.size(); i++) if (P.leaves[i].kind == 1) { E.dirty[i] = 1; E.ensure_final((int)i); }
+    E.close_window();
+    E.lu(0);
+    for (size_t i = 0; i < in.size(); i++) E.ensure_final((int)i);
+    E.close_window();
+    P.n_slots = E.next_slot;
+    // the two solves: fresh dependency state, the factors are read only
+    for (int pass = 0; pass < 2; pass++) {
+        for (Track &t : E.trU) t = Track();
+        for (Track &t : E.trV) t = Track();
+        for (Track &t : E.trD) t = Track();
+        E.window_base = 1; E.max_level = 0; E.scratch_used = 0;
+        Track rhs;
+        rhs.init(E.cell0[0], E.cell1[0] - E.cell0[0]);
+        Thin X;
+        X.base = 0; X.ld = -1; X.pos0 = 0; X.space = SP_RHS; X.tr = &rhs;
+        int64_t keep[T_NTYPES];
+        for (int q = 0; q < T_NTYPES; q++) keep[q] = P.counts[q];
+        if (pass == 0) { E.thin_solve_l(0, X, -2, 0); E.thin_solve_u(0, X, -2, 0); }
+        else { E.thin_solve_ut(0, X, -2, 0); E.thin_solve_lt(0, X, -2, 0); }
+        for (int q = 0; q < T_NTYPES; q++) P.counts[q] = keep[q];
+        E.finish_program(E.cur, pass == 0 ? P.solve_n : P.solve_t);
+    }
+    P.plan_seconds = wall_seconds() - t0;
+    return plan.release();
+}
+
+} // namespace hlu
+} // namespace hm

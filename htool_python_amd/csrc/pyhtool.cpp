@@ -869,6 +869,62 @@ PYBIND11_MODULE(Htool, m) {
             return out;
         }, "cluster"_a, "partition_number"_a = -1, "tile_max"_a = 128);
 
+    // the plan of the hierarchical LU (host only; tests hand its task lists to the CPU checker under oracle/)
+    struct PyHluPlan {
+        htool_hlu_plan *p = nullptr;
+        std::shared_ptr<ClusterRoot> owner;
+        ~PyHluPlan() { htool_hlu_plan_free(p); }
+    };
+    py::class_<PyHluPlan, std::shared_ptr<PyHluPlan>>(m, "HLUPlan")
+        .def(py::init([](const PyCluster &c, py::array_t<int32_t, py::array::c_style | py::array::forcecast> rects5, double epsilon, int cap_min, int cap_max,
+                         long long window_scratch_elems, long long window_tasks, double cap_factor) {
+                 if (rects5.ndim() != 2 || rects5.shape(1) != 5) throw std::runtime_error("HLUPlan: rects must be (n_leaves, 5) int32: t_off, m, s_off, n, rank");
+                 auto pl = std::make_shared<PyHluPlan>();
+                 pl->owner = c.owner;
+                 {
+                     py::gil_scoped_release nogil;
+                     check(htool_hlu_plan_create(c.owner->root, rects5.shape(0), rects5.data(), epsilon, cap_min, cap_max, cap_factor, window_scratch_elems, window_tasks, &pl->p));
+                 }
+                 return pl;
+             }), "cluster"_a, "rects"_a, "epsilon"_a = 1e-3, "cap_min"_a = 0, "cap_max"_a = 0, "window_scratch_elems"_a = 0, "window_tasks"_a = 0, "cap_factor"_a = 0.0)
+        .def("info", [](const PyHluPlan &s) {
+                py::array_t<int64_t> out(23);
+                check(htool_hlu_plan_info(s.p, out.mutable_data(), 23));
+                return out;
+            })
+        .def("program", [](const PyHluPlan &s, int which) { // copies: (tasks as bytes (n, 96), buckets as int64 (n, 5), runs, scratch elements)
+                const void *tasks, *buckets;
+                const int64_t *seg;
+                int64_t nt, nb, ns, scratch;
+                check(htool_hlu_plan_program(s.p, which, &tasks, &nt, &buckets, &nb, &seg, &ns, &scratch));
+                py::array_t<uint8_t> t({(py::ssize_t)nt, (py::ssize_t)96});
+                std::memcpy(t.mutable_data(), tasks, (size_t)nt * 96);
+                py::array_t<int64_t> b({(py::ssize_t)nb, (py::ssize_t)5});
+                std::memcpy(b.mutable_data(), buckets, (size_t)nb * 40);
+                py::array_t<int64_t> g((py::ssize_t)ns);
+                std::memcpy(g.mutable_data(), seg, (size_t)ns * 8);
+                return py::make_tuple(t, b, g, scratch);
+            }, "which"_a)
+        .def("debug_execute", [](const PyHluPlan &s, int first, int last, py::array_t<double> factor, py::array_t<double> diag, py::array_t<int32_t> rank,
+                                 py::array_t<double> norm0, py::array_t<double> norm2, py::array_t<int64_t> counters, py::object rhs, long long ld_rhs, int nrhs) {
+                double *r = nullptr;
+                if (!rhs.is_none()) r = rhs.cast<py::array_t<double>>().mutable_data();
+                py::gil_scoped_release nogil;
+                check(htool_hlu_debug_execute(s.p, first, last, factor.mutable_data(), diag.mutable_data(), rank.mutable_data(), norm0.mutable_data(), norm2.mutable_data(),
+                                              counters.mutable_data(), r, ld_rhs, nrhs));
+            }, "first"_a, "last"_a, "factor"_a, "diag"_a, "rank"_a, "norm0"_a, "norm2"_a, "counters"_a, "rhs"_a = py::none(), "ld_rhs"_a = 0, "nrhs"_a = 0)
+        .def("tables", [](const PyHluPlan &s) {
+                const void *leaves, *diags;
+                int64_t info[3];
+                check(htool_hlu_plan_info(s.p, info, 3));
+                check(htool_hlu_plan_tables(s.p, &leaves, &diags));
+                py::array_t<uint8_t> l({(py::ssize_t)info[1], (py::ssize_t)48});
+                std::memcpy(l.mutable_data(), leaves, (size_t)info[1] * 48);
+                py::array_t<uint8_t> d({(py::ssize_t)info[2], (py::ssize_t)24});
+                std::memcpy(d.mutable_data(), diags, (size_t)info[2] * 24);
+                return py::make_tuple(l, d);
+            });
+
     declare_coefficient_classes<double>(m, "", "IGenerator", "VirtualGenerator", "VirtualLowRankGenerator", "NativeGenerator");
     declare_coefficient_classes<std::complex<double>>(m, "Complex", "IComplexGenerator", "ComplexVirtualGenerator", "VirtualComplexLowRankGenerator", "ComplexNativeGenerator");
 }

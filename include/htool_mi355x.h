@@ -370,7 +370,29 @@ int htool_debug_sort_pairs(uint32_t *keys_dev, uint32_t *values_dev, int64_t n, 
 int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_complex, const void *h1_dev, const void *t2_dev, int j, const double *mask_dev,
                              void *coef_dev, int scale, const void *V_dev, int64_t ld_basis, int64_t ld_rhs, void *stream);
 
+/* ---- hierarchical LU: the plan (src/htool/hmatrix/hmatrix.hpp:58-94: htool::lu_factorization / lu_solve / cholesky_*) ----
+ * htool_hmatrix_lu_factorization / _cholesky_factorization factorise hierarchically on the device (csrc/hlu_device.hip): the
+ * block-recursive algorithm is run once on the host on the block structure alone and turned into levels of leaf tasks
+ * (csrc/hlu_symbolic.cpp, csrc/hlu.hpp).  The entries below expose that PLAN for tests: rects5 = (t_off, m, s_off, n, rank) per leaf
+ * of a square operator on the cluster tree of `root`, rank < 0 for a dense leaf; the plan is host data only (no device needed).
+ * htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
+ * each, struct hm::hlu::Task), launch buckets and target runs of one window of the factorisation (which >= 0) or of the
+ * solves (-1: 'N', -2: 'T'); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
+typedef struct htool_hlu_plan htool_hlu_plan;
+int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int32_t *rects5, double epsilon, int cap_min, int cap_max, double cap_factor,
+                          int64_t window_scratch_elems, int64_t window_tasks, htool_hlu_plan **out);
+int htool_hlu_plan_info(const htool_hlu_plan *plan, int64_t *out, int n_out);
+int htool_hlu_plan_program(const htool_hlu_plan *plan, int which, const void **tasks, int64_t *n_tasks, const void **buckets, int64_t *n_buckets,
+                           const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems);
+int htool_hlu_plan_tables(const htool_hlu_plan *plan, const void **leaves, const void **diags);
+void htool_hlu_plan_free(htool_hlu_plan *plan);
+/* diagnostic: windows first..last of the plan's factorisation (first >= 0), or one of its solves (first = -1 'N', -2 'T') executed by
+ * the DEVICE kernels on host arrays laid out as the plan says (uploaded, run, downloaded) -- the counterpart of the CPU checker
+ * oracle/hlu_exec.cpp, which tests feed the same arrays.  counters: 8 values. */
+int htool_hlu_debug_execute(const htool_hlu_plan *plan, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,
+                            int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs);
+
 #ifdef __cplusplus
 }
 #endif
-#endif
+#endif /* HTOOL_MI355X_H */

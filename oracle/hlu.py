@@ -1,0 +1,115 @@
+"""ctypes front-end of the CPU checker of the hierarchical LU (oracle/hlu_exec.cpp).
+
+TEST INFRASTRUCTURE ONLY.  Executes the task lists of an `Htool.HLUPlan` (the product's plan of the block-recursive
+H-LU, htool_python_amd/csrc/hlu_symbolic.cpp) on host arrays with plain loops, so that the algorithm and its dependency
+levels can be checked without a GPU, and so that the device kernels have something to be compared with.  The pin is
+the dense solve of the same operator (numpy): the reference's H-LU lives in lib/htool, which is absent ("parity
+unpinned", see hlu_exec.cpp).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libhlu_exec.so")
+_lib = None
+
+TASK = np.dtype([("type", "i4"), ("flags", "i4"), ("level", "i4"), ("leaf", "i4"), ("kref", "i4"), ("kconst", "i4"), ("m", "i4"), ("n", "i4"),
+                 ("r0", "i4"), ("c0", "i4"), ("a_ld", "i4"), ("b_ld", "i4"), ("x_ld", "i4"), ("y_ld", "i4"),
+                 ("a", "i8"), ("b", "i8"), ("x", "i8"), ("y", "i8"), ("w", "i8")])
+LEAF = np.dtype([("t_off", "i4"), ("m", "i4"), ("s_off", "i4"), ("n", "i4"), ("kind", "i4"), ("cap", "i4"), ("u", "i8"), ("v", "i8"), ("diag", "i4"), ("rank0", "i4")])
+DIAG = np.dtype([("leaf", "i4"), ("m", "i4"), ("linv", "i8"), ("uinv", "i8")])
+assert TASK.itemsize == 96 and LEAF.itemsize == 48 and DIAG.itemsize == 24
+INFO = ["n", "leaves", "diag_leaves", "factor_elems", "diag_elems", "scratch_elems", "rank_slots", "windows", "factor_tasks", "factor_launches", "factor_levels",
+        "solve_tasks", "solve_launches", "solve_levels", "plan_us", "solve_t_tasks", "FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF"]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "hlu_exec.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i64, ci, cd, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_uint64
+        L.hluo_run.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, ci, vp, vp, vp, cd, vp, u64]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class HostLU:
+    """The factorisation of a plan on host arrays.  `leaf_data(i)` -> (D, None) or (U m x r, V r x n) of leaf i, in the order
+    of the rects the plan was made from."""
+
+    def __init__(self, plan, leaf_data, eps, shuffle=0, run=True):
+        self.plan, self.eps = plan, float(eps)
+        self.info = dict(zip(INFO, [int(x) for x in plan.info()]))
+        l, d = plan.tables()
+        self.leaves = np.ascontiguousarray(l).view(LEAF).ravel()
+        self.diags = np.ascontiguousarray(d).view(DIAG).ravel()
+        I = self.info
+        self.factor = np.zeros(max(I["factor_elems"], 1))
+        self.diag = np.zeros(max(I["diag_elems"], 1))
+        self.scratch = np.zeros(max(I["scratch_elems"], 1))
+        self.rank = np.zeros(max(I["rank_slots"], 1), dtype=np.int32)
+        self.norm0 = np.full(max(I["leaves"], 1), -1.0)
+        self.norm2 = np.zeros(max(I["leaves"], 1))
+        self.counters = np.zeros(8, dtype=np.int64)
+        for i, L in enumerate(self.leaves):
+            A, B = leaf_data(i)
+            m, n = int(L["m"]), int(L["n"])
+            if L["kind"] == 0:
+                self.factor[L["u"]:L["u"] + m * n] = np.asarray(A).T.ravel()  # column-major, ld = m
+            else:
+                r = A.shape[1]
+                assert r == L["rank0"] and r <= L["cap"]
+                self.factor[L["u"]:L["u"] + m * r] = np.asarray(A).T.ravel()
+                self.factor[L["v"]:L["v"] + n * r] = np.asarray(B).ravel()
+                self.rank[i] = r
+        if run:
+            for w in range(I["windows"]):
+                self.run_window(w, shuffle)
+
+    def run_window(self, w, shuffle=0):
+        self._run(w, None, 0, shuffle)
+
+    def leaf_dense(self, i):
+        """The block a leaf stands for now (dense copy), from the factor arena."""
+        L = self.leaves[i]
+        m, n = int(L["m"]), int(L["n"])
+        if L["kind"] == 0:
+            return self.factor[L["u"]:L["u"] + m * n].reshape(n, m).T
+        r = int(self.rank[i])
+        return self.factor[L["u"]:L["u"] + m * r].reshape(r, m).T @ self.factor[L["v"]:L["v"] + n * r].reshape(r, n)
+
+    def _run(self, which, rhs, nrhs, shuffle=0):
+        t, b, g, _ = self.plan.program(which)
+        t, b, g = np.ascontiguousarray(t), np.ascontiguousarray(b), np.ascontiguousarray(g)
+        lib().hluo_run(_p(t), t.shape[0], _p(b), b.shape[0], _p(g), _p(self.leaves), _p(self.diags), _p(self.factor), _p(self.diag), _p(self.scratch),
+                       _p(rhs), 0 if rhs is None else self.info["n"], nrhs,
+                       _p(self.rank), _p(self.norm0), _p(self.norm2), self.eps, _p(self.counters), shuffle)
+
+    def solve(self, b_cluster, trans="N", shuffle=0):
+        """b in CLUSTER numbering, (n,) or (n, q); returns A^-1 b (or A^-T b)."""
+        B = np.array(b_cluster, dtype=np.float64, order="F", ndmin=2)
+        if B.shape[0] == 1 and np.ndim(b_cluster) == 1:
+            B = np.asfortranarray(B.T)
+        X = np.asfortranarray(B.copy())
+        flat = X.ravel(order="F")  # (a view of X: column-major, ld = n)
+        assert np.shares_memory(flat, X)
+        self._run(-1 if trans == "N" else -2, flat, X.shape[1], shuffle)
+        return X[:, 0] if np.ndim(b_cluster) == 1 else X
+
+    def ranks(self):
+        return self.rank[: self.info["leaves"]].copy()
