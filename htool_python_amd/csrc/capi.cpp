@@ -638,23 +638,45 @@ static DenseFactor *factor_of(htool_hmatrix *h, int kind, char uplo) {
     else { f->ar.resize((size_t)n * n); densify(H, f->ar.data(), 1); if (kind == 1) lu_factor(n, f->ar, f->piv); else chol_factor(n, f->ar, uplo); }
     return f.release();
 }
-static void factorise(htool_hmatrix *h, int kind, char uplo, double shift, bool device_only = false) {
-    if (device_only || factor_on_device(h->H)) {
-        log_message(LOG_WARNING, strprintf("%s: dense fallback on the device (a dense copy of the operator is factorised by the dense solver library; hierarchical LU is not part of this engine)",
-                                           kind == 1 ? "lu_factorization" : "cholesky_factorization"));
-        DeviceDenseFactor *f = device_dense_factor(h->H, kind, uplo, shift);
-        device_dense_factor_free(h->dfactor);
-        h->dfactor = f;
-        delete (DenseFactor *)h->factor;
-        h->factor = nullptr;
-        return;
-    }
-    HM_CHECK(shift == 0.0, "factorization with a diagonal shift is implemented on the device path only");
-    DenseFactor *f = factor_of(h, kind, uplo);
+// Round 4: the factorisation is HIERARCHICAL on the device (hlu_device.hip) whenever the operator is one it covers -- real, square on
+// one cluster (sub)tree, tolerance >= 1e-7; the dense factorisations above / in dense_device.hip are the fallback for the others
+// (complex operators, tighter tolerances) and for HTOOL_FACTOR=dense (or HTOOL_DENSE_FACTOR=host|device, which names a dense
+// path).  HTOOL_FACTOR=hlu refuses to fall back.
+static void drop_factors(htool_hmatrix *h) {
     delete (DenseFactor *)h->factor;
-    h->factor = f;
+    h->factor = nullptr;
     device_dense_factor_free(h->dfactor);
     h->dfactor = nullptr;
+    device_hlu_free(h->hfactor);
+    h->hfactor = nullptr;
+}
+static void factorise(htool_hmatrix *h, int kind, char uplo, double shift, bool device_only = false) {
+    const char *mode_env = getenv("HTOOL_FACTOR");
+    const std::string mode = mode_env ? mode_env : "";
+    const bool dense_forced = mode == "dense" || (mode != "hlu" && getenv("HTOOL_DENSE_FACTOR") != nullptr);
+    if (!dense_forced) {
+        try {
+            DeviceHLU *f = device_hlu_factor(h->H, kind, shift, 0.0);
+            drop_factors(h);
+            h->hfactor = f;
+            return;
+        } catch (const Error &e) {
+            if (mode == "hlu") throw;
+            log_message(LOG_WARNING, strprintf("%s: the hierarchical factorisation does not cover this operator (%s) -- dense fallback", kind == 1 ? "lu_factorization" : "cholesky_factorization", e.what()));
+        }
+    }
+    if (device_only || factor_on_device(h->H)) {
+        log_message(LOG_WARNING, strprintf("%s: dense fallback on the device (a dense copy of the operator is factorised by the dense solver library)",
+                                           kind == 1 ? "lu_factorization" : "cholesky_factorization"));
+        DeviceDenseFactor *f = device_dense_factor(h->H, kind, uplo, shift);
+        drop_factors(h);
+        h->dfactor = f;
+        return;
+    }
+    HM_CHECK(shift == 0.0, "factorization with a diagonal shift is implemented on the device paths only");
+    DenseFactor *f = factor_of(h, kind, uplo);
+    drop_factors(h);
+    h->factor = f;
 }
 int htool_hmatrix_lu_factorization(htool_hmatrix *h) {
     API_BEGIN
@@ -675,6 +697,11 @@ int htool_hmatrix_cholesky_factorization(htool_hmatrix *h, char uplo) {
 }
 int htool_hmatrix_factor_solve_device(const htool_hmatrix *h, int kind, char trans, void *B_dev, int64_t ldb, int mu, void *stream) {
     API_BEGIN
+    if (h->hfactor) {
+        HM_CHECK(device_hlu_kind(h->hfactor) == kind, kind == 1 ? "lu_solve: call lu_factorization first" : "cholesky_solve: call cholesky_factorization first");
+        device_hlu_solve(h->hfactor, trans, B_dev, (long long)ldb, mu, stream);
+        return 0;
+    }
     HM_CHECK(h->dfactor != nullptr && device_dense_factor_kind(h->dfactor) == kind, "factor_solve_device: no device factorisation of that kind (call lu_factorization / cholesky_factorization first; "
                                                                                      "operators of at most 20000 unknowns are factorised on the host unless HTOOL_DENSE_FACTOR=device)");
     device_dense_solve(h->dfactor, trans, B_dev, (long long)ldb, mu, stream ? stream : (void *)nullptr);
@@ -688,6 +715,12 @@ int htool_hmatrix_to_dense_device(const htool_hmatrix *h, void *out_dev, int64_t
 }
 int htool_hmatrix_factor_solve(const htool_hmatrix *h, int kind, char trans, void *B, int mu) {
     API_BEGIN
+    if (h->hfactor) {
+        HM_CHECK(device_hlu_kind(h->hfactor) == kind, kind == 1 ? "lu_solve: call lu_factorization first" : "cholesky_solve: call cholesky_factorization first");
+        HM_CHECK(trans == 'N' || trans == 'T', "factor solve: trans must be 'N' or 'T'");
+        device_hlu_solve_host(h->H, h->hfactor, trans, B, mu);
+        return 0;
+    }
     if (h->dfactor) {
         HM_CHECK(device_dense_factor_kind(h->dfactor) == kind, kind == 1 ? "lu_solve: call lu_factorization first" : "cholesky_solve: call cholesky_factorization first");
         HM_CHECK(trans == 'N' || trans == 'T', "factor solve: trans must be 'N' or 'T'");
@@ -747,6 +780,17 @@ int htool_cluster_tiles(const htool_cluster *root, int partition_number, int til
 htool_hmatrix::~htool_hmatrix() {
     delete (DenseFactor *)factor;
     device_dense_factor_free(dfactor);
+    device_hlu_free(hfactor);
+}
+extern "C" int htool_hmatrix_factorization_info(const htool_hmatrix *h, int64_t *out17, double *seconds4) {
+    API_BEGIN
+    HM_CHECK(h && out17, "htool_hmatrix_factorization_info: null argument");
+    for (int i = 0; i < 17; i++) out17[i] = 0;
+    if (seconds4) for (int i = 0; i < 4; i++) seconds4[i] = 0;
+    if (h->hfactor) { out17[0] = 3; device_hlu_stats(h->hfactor, out17 + 1, seconds4); }
+    else if (h->dfactor) out17[0] = 2;
+    else if (h->factor) out17[0] = 1;
+    API_END
 }
 extern "C" {
 int64_t htool_hmatrix_leaf_count(const htool_hmatrix *h) { return (int64_t)h->H.leaf_count(); }

@@ -11,12 +11,14 @@ struct htool_cluster {}; // never instantiated: handles are hm::ClusterHandle
 struct htool_generator {
     hm::Generator g;
 };
+struct DeviceHLU;         // hierarchical LU of an operator, on the device (hlu_device.hip)
 struct DeviceDenseFactor; // dense LU / Cholesky of an operator, held on the device (dense_device.hip)
 struct htool_hmatrix {
     hm::HMatrix H;
     hm::ClusterHandle *tch = nullptr, *sch = nullptr;
     void *factor = nullptr; // DenseFactor of the host fallback for lu/cholesky (capi.cpp)
     DeviceDenseFactor *dfactor = nullptr; // ... or the device one (larger operators, partition-built blocks)
+    struct ::DeviceHLU *hfactor = nullptr;  // the hierarchical factorisation (hlu_device.hip): the default
     ~htool_hmatrix();
 };
 // dense_device.hip

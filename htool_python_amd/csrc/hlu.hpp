@@ -79,7 +79,7 @@ struct Program {
 struct Params {
     double eps = 1e-3;   // relative truncation tolerance of the low-rank arithmetic
     int cap_min = 16, cap_max = 64, cap_extra = 8; // capacity of a leaf: clamp(ceil(cap_factor rank) + cap_extra, cap_min, cap_max)
-    double cap_factor = 2.0;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
+    double cap_factor = 2.5;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
     int64_t window_scratch_elems = (int64_t)1 << 29; // a window of the task stream may hold this much scratch (4 GB of doubles)
     int64_t window_tasks = (int64_t)1 << 23;
 };
@@ -87,7 +87,8 @@ struct Params {
 struct Plan {
     const ClusterTree *tree = nullptr;
     Params params;
-    int n = 0;
+    int root = 0;  // cluster node the operator is built on (the root, or a partition: the diagonal block of a rank)
+    int n = 0, pos0 = 0; // its size and first position: row i of a right-hand side is cluster position pos0 + i
     std::vector<Leaf> leaves;
     std::vector<Diag> diags;
     int64_t factor_elems = 0, diag_elems = 0, scratch_elems = 0; // arena sizes (elements)
@@ -100,7 +101,7 @@ struct Plan {
 
 // input: the leaves of a square H-matrix on one cluster tree (both triangles), rank < 0: dense
 struct LeafIn { int t_node, s_node, rank; };
-Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &leaves, const Params &P);
+Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &leaves, const Params &P, int root = 0);
 
 } // namespace hlu
 } // namespace hm

@@ -21,7 +21,10 @@
 // lu_solve replays the plan's solve program (forward and backward sweep over the leaves) on the caller's block of
 // right-hand sides.
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "capi_internal.hpp"
 #include "device_internal.hpp"
@@ -215,7 +218,7 @@ __device__ void jacobi_lds(double *M, double *J, int K, int KS, int *flag) {
     }
 }
 
-__device__ __forceinline__ int keep_max(const Leaf &L) { return L.cap - max(4, L.cap / 4); }
+__device__ __forceinline__ int keep_max(const Leaf &L) { return L.cap - max(4, L.cap / 6); }
 
 // U V^T with K = rank[l] columns -> the truncated form (hlu.hpp); the whole workgroup.  sm: 4 matrices of Kc x KS, then vectors.
 __device__ void recompress(const Ctx &c, int l, const Leaf &L, double *sm, int Kc) {
@@ -299,8 +302,8 @@ __device__ void recompress(const Ctx &c, int l, const Leaf &L, double *sm, int K
             if (tail + sig[ord[k]] <= c.eps * c.eps * tot) { tail += sig[ord[k]]; newr = k; }
             else break;
         }
-        c.counters[1]++;
-        if (newr > keep_max(L)) { newr = keep_max(L); c.counters[0]++; }
+        atomicAdd((unsigned long long *)&c.counters[1], 1ull);
+        if (newr > keep_max(L)) { newr = keep_max(L); atomicAdd((unsigned long long *)&c.counters[0], 1ull); }
         double kept = 0;
         for (int q = 0; q < newr; q++) kept += sig[ord[q]];
         c.norm2[l] = kept;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void hlu_update_kernel(Ctx c, const Task *task
                 V[(long long)(fill + col) * L.n + j] = (r >= 0 && r < t.n) ? (zt ? Z[(long long)r * t.y_ld + q] : Z[r + (long long)q * t.y_ld]) : 0.0;
             }
             __syncthreads();
-            if (tid == 0) { c.rank[t.leaf] = fill + take; c.counters[2] += take; }
+            if (tid == 0) { c.rank[t.leaf] = fill + take; atomicAdd((unsigned long long *)&c.counters[2], (unsigned long long)take); }
             __syncthreads();
             done += take;
         }
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void hlu_ddprod_kernel(Ctx c, const Task *task
         __syncthreads();
         k++;
     }
-    if (tid == 0) { c.rank[t.kref] = k; c.counters[3] += k; }
+    if (tid == 0) { c.rank[t.kref] = k; atomicAdd((unsigned long long *)&c.counters[3], (unsigned long long)k); }
 }
 
 __global__ __launch_bounds__(256) void hlu_getrf_kernel(Ctx c, const Task *tasks) {
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void hlu_getrf_kernel(Ctx c, const Task *tasks
             __syncthreads();
         }
         const int p = ridx[0];
-        if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) c.counters[4]++; }
+        if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) atomicAdd((unsigned long long *)&c.counters[4], 1ull); }
         __syncthreads();
         if (p != j) for (int col = tid; col < m; col += 256) { const double a = A[j + (long long)col * m]; A[j + (long long)col * m] = A[p + (long long)col * m]; A[p + (long long)col * m] = a; }
         __syncthreads();
@@ -546,7 +549,11 @@ void attributes_once() {
 // one program, bucket by bucket, on `st`; tasks / runs already on the device
 void run_program(const Program &G, const DevProgram &dp, const Ctx &c, const std::vector<Leaf> &leaves, hipStream_t st) {
     attributes_once();
+    long long limit = -1; // diagnostic: HTOOL_HLU_DEBUG_BUCKETS=<n> stops every program after its first n launches
+    if (const char *e = getenv("HTOOL_HLU_DEBUG_BUCKETS")) limit = atoll(e);
+    long long launched = 0;
     for (const Bucket &b : G.buckets) {
+        if (limit >= 0 && launched++ >= limit) break;
         const unsigned n = (unsigned)(b.end - b.begin);
         const Task *t0 = dp.tasks + b.begin;
         switch (b.type) {
@@ -655,13 +662,14 @@ void hlu_allocate(DeviceHLU &f) {
 }
 
 // windows [first, last] of the factorisation on the stream; the tasks of a window are uploaded while the previous one runs
-void hlu_run_windows(DeviceHLU &f, int first, int last, hipStream_t st) {
+void hlu_run_windows(DeviceHLU &f, int first, int last, hipStream_t st, double *scratch_host = nullptr) {
     const Plan &P = *f.plan;
     size_t max_tasks = 1, max_seg = 1;
     for (int w = first; w <= last; w++) { max_tasks = std::max(max_tasks, P.factor[(size_t)w].tasks.size()); max_seg = std::max(max_seg, P.factor[(size_t)w].seg.size()); }
     DevBuf tasks[2], seg[2], scratch;
     for (int q = 0; q < 2; q++) { tasks[q].alloc(max_tasks * sizeof(Task)); seg[q].alloc(max_seg * sizeof(int64_t)); }
     scratch.alloc((size_t)P.scratch_elems * 8);
+    if (scratch_host) HIP_OK(hipMemcpy(scratch.p, scratch_host, (size_t)P.scratch_elems * 8, hipMemcpyHostToDevice));
     const Ctx c = f.ctx(scratch.as<double>(), nullptr, 0, 0);
     hipStream_t up = nullptr;
     HIP_OK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
@@ -684,6 +692,7 @@ void hlu_run_windows(DeviceHLU &f, int first, int last, hipStream_t st) {
         }
         HIP_OK(hipStreamSynchronize(st));
         HIP_OK(hipStreamSynchronize(up));
+        if (scratch_host) HIP_OK(hipMemcpy(scratch_host, scratch.p, (size_t)P.scratch_elems * 8, hipMemcpyDeviceToHost));
     } catch (...) {
         (void)hipDeviceSynchronize();
         for (int q = 0; q < 2; q++) { if (uploaded[q]) (void)hipEventDestroy(uploaded[q]); if (done[q]) (void)hipEventDestroy(done[q]); }
@@ -720,12 +729,135 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
     run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, stream ? (hipStream_t)stream : f->stream);
 }
 
+// ---- the factorisation of an operator -----------------------------------------------------------------------------------------
+// kind: 1 LU, 2 Cholesky (the same factorisation: the hierarchical arithmetic here is the LU; a symmetric operator stored as one
+// triangle gets its other triangle as transposed leaves).  eps_lu <= 0: a tenth of the operator's epsilon (HTOOL_HLU_EPS overrides),
+// so that the error of a solve stays below the operator's own epsilon -- the bar of the reference's tests (tests/test_hmatrix.py:104).
+// Throws hm::Error when the operator is not one this factorisation covers (the caller falls back to the dense one).
+DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double eps_lu) {
+    DeviceHMatrix *D = H.dev;
+    HM_CHECK(D != nullptr, "H-matrix has no device data");
+    HM_CHECK(!H.is_complex, "hierarchical LU: complex operators are factorised by the dense fallback");
+    HM_CHECK(H.tc == H.sc && H.t_root == H.s_root && H.row_size == H.col_size, "hierarchical LU needs a square H-matrix on one cluster (sub)tree");
+    const double t_begin = wall_seconds();
+    HIP_OK(hipSetDevice(D->device));
+    const ClusterTree &T = *H.tc;
+    const std::vector<BlockRec> &blocks = H.blocks();
+    std::vector<LeafIn> in;
+    in.reserve(blocks.size() * (H.one_triangle ? 2 : 1));
+    for (const BlockRec &b : blocks) in.push_back({b.t_node, b.s_node, b.rank < 0 ? -1 : b.rank});
+    std::vector<int2> mirrors; // (stored leaf, its transposed twin)
+    if (H.one_triangle)
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (blocks[i].t_node != blocks[i].s_node) {
+                mirrors.push_back(make_int2((int)i, (int)in.size()));
+                in.push_back({blocks[i].s_node, blocks[i].t_node, blocks[i].rank < 0 ? -1 : blocks[i].rank});
+            }
+    Params prm;
+    prm.eps = eps_lu > 0 ? eps_lu : 0.1 * H.params.epsilon;
+    if (const char *e = getenv("HTOOL_HLU_EPS")) if (atof(e) > 0) prm.eps = atof(e);
+    HM_CHECK(prm.eps >= 1e-7, "hierarchical LU: tolerances below 1e-7 are beyond the Gram-matrix truncation of the low-rank arithmetic (the dense factorisation takes over)");
+    const double eb = std::min(std::max(H.params.epsilon, 1e-12), 0.5);
+    prm.cap_factor = 2.5 * std::max(1.0, std::log(prm.eps) / std::log(eb)); // (measured: the ranks of the factors reach 2.5-3 x those of the operator at a tenth of its tolerance)
+    if (const char *e = getenv("HTOOL_HLU_CAP_FACTOR")) if (atof(e) > 0) prm.cap_factor = atof(e);
+    if (const char *e = getenv("HTOOL_HLU_WINDOW_MB")) if (atof(e) > 0) prm.window_scratch_elems = (int64_t)(atof(e) * 1e6 / 8);
+    std::unique_ptr<DeviceHLU> f(new DeviceHLU);
+    f->plan = make_plan(T, in, prm, H.t_root);
+    const Plan &P = *f->plan;
+    for (const Leaf &L : P.leaves) if (L.kind == 0) HM_CHECK(L.m <= HLU_MAX_DIM && L.n <= HLU_MAX_DIM, "hierarchical LU: a dense leaf has more rows or columns than the kernels stage on chip");
+    f->device = D->device; f->n = P.n; f->asked = kind; f->stream = D->stream; f->perm = D->perm_t;
+    f->whole = H.t_root == 0 && !H.local_numbering;
+    f->seconds[0] = P.plan_seconds;
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        const double need = ((double)P.factor_elems + P.diag_elems + P.scratch_elems) * 8 + 2.0 * 96 * (double)prm.window_tasks + 512e6;
+        if (need > (double)free_b) (void)device_release_workspace();
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        HM_CHECK(need <= (double)free_b, strprintf("hierarchical LU: %.1f GB needed (factors %.1f, scratch %.1f), %.1f GB free", need / 1e9, P.factor_elems * 8e-9, P.scratch_elems * 8e-9, free_b / 1e9));
+    }
+    hlu_allocate(*f);
+    const double t_unpack = wall_seconds();
+    {
+        std::vector<int64_t> ids(blocks.size()), uo(blocks.size()), vo(blocks.size());
+        for (size_t i = 0; i < blocks.size(); i++) { ids[i] = (int64_t)i; uo[i] = P.leaves[i].u; vo[i] = P.leaves[i].v; }
+        device_unpack_leaves(H, (int64_t)ids.size(), ids.data(), uo.data(), vo.data(), f->factor);
+    }
+    const Ctx c0 = f->ctx(nullptr, nullptr, 0, 0);
+    if (!mirrors.empty()) {
+        DevBuf mp;
+        mp.alloc(mirrors.size() * sizeof(int2));
+        HIP_OK(hipMemcpy(mp.p, mirrors.data(), mirrors.size() * sizeof(int2), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(hlu_mirror_kernel, dim3((unsigned)mirrors.size()), dim3(256), 0, D->stream, c0, mp.as<int2>(), 0);
+        HIP_OK(hipStreamSynchronize(D->stream));
+    }
+    if (shift != 0.0 && !P.diags.empty()) hipLaunchKernelGGL(hlu_shift_kernel, dim3((unsigned)P.diags.size()), dim3(128), 0, D->stream, c0, (int)P.diags.size(), shift);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(D->stream));
+    f->seconds[1] = wall_seconds() - t_unpack;
+    const double t_fact = wall_seconds();
+    hlu_run_windows(*f, 0, (int)P.factor.size() - 1, D->stream);
+    f->seconds[2] = wall_seconds() - t_fact;
+    hlu_upload_solves(*f);
+    long long counters[8];
+    HIP_OK(hipMemcpy(counters, f->counters, sizeof(counters), hipMemcpyDeviceToHost));
+    HM_CHECK(counters[4] == 0, kind == 1 ? "lu_factorization: singular matrix (zero pivot in a diagonal leaf)" : "cholesky_factorization: singular matrix (zero pivot in a diagonal leaf)");
+    int64_t tasks = 0, launches = 0, rank_sum = 0, lr_rows = 0;
+    for (const Program &w : P.factor) { tasks += (int64_t)w.tasks.size(); launches += (int64_t)w.buckets.size(); }
+    {
+        std::vector<int> r(P.leaves.size());
+        HIP_OK(hipMemcpy(r.data(), f->rank, r.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < r.size(); i++) if (P.leaves[i].kind == 1) { rank_sum += (int64_t)r[i] * (P.leaves[i].m + P.leaves[i].n); lr_rows += P.leaves[i].m + P.leaves[i].n; }
+    }
+    f->seconds[3] = wall_seconds() - t_begin;
+    int64_t *s = f->stats;
+    s[0] = P.n; s[1] = (int64_t)P.leaves.size(); s[2] = tasks; s[3] = launches; s[4] = (int64_t)P.factor.size();
+    s[5] = (P.factor_elems + P.diag_elems) * 8; s[6] = P.scratch_elems * 8; s[7] = counters[0]; s[8] = counters[1]; s[9] = counters[2]; s[10] = counters[3];
+    s[11] = (int64_t)P.solve_n.tasks.size(); s[12] = (int64_t)P.solve_n.buckets.size(); s[13] = rank_sum; s[14] = lr_rows; s[15] = (int64_t)(prm.eps * 1e12);
+    if (counters[0] > 0)
+        log_message(LOG_WARNING, strprintf("hierarchical LU: %lld truncations were cut at the capacity of their leaf (accuracy below the asked %.1e: raise HTOOL_HLU_CAP_FACTOR, now %.2f)",
+                                           counters[0], prm.eps, prm.cap_factor));
+    log_message(LOG_INFO, strprintf("hierarchical %s of the %d x %d operator: plan %.3f s (%lld tasks, %lld launches, %d windows), leaves into the factor arena %.3f s, factorisation %.3f s; "
+                                    "factors %.2f GB, scratch %.2f GB, eps %.1e, mean rank %.1f", kind == 1 ? "LU" : "Cholesky (as LU)", P.n, P.n, f->seconds[0], (long long)tasks, (long long)launches,
+                                    (int)P.factor.size(), f->seconds[1], f->seconds[2], s[5] / 1e9, s[6] / 1e9, prm.eps, lr_rows ? (double)rank_sum / lr_rows : 0.0));
+    // the programs of the factorisation are not needed any more (the solves are on the device)
+    for (Program &w : f->plan->factor) { std::vector<Task>().swap(w.tasks); std::vector<int64_t>().swap(w.seg); }
+    return f.release();
+}
+
+void device_hlu_stats(const DeviceHLU *f, int64_t *out16, double *seconds4) {
+    HM_CHECK(f != nullptr, "no hierarchical factorisation");
+    if (out16) for (int i = 0; i < 16; i++) out16[i] = f->stats[i];
+    if (seconds4) for (int i = 0; i < 4; i++) seconds4[i] = f->seconds[i];
+}
+
+// host right-hand sides in USER numbering (the reference's lu_solve / cholesky_solve): to cluster numbering on the device, solved, back
+void device_hlu_solve_host(const HMatrix &H, const DeviceHLU *f, char trans, void *B, int mu) {
+    const int n = f->n;
+    if (n == 0 || mu == 0) return;
+    DeviceHMatrix *D = H.dev;
+    HIP_OK(hipSetDevice(f->device));
+    DevBuf d_in, d_cl;
+    d_in.alloc((size_t)n * mu * 8);
+    d_cl.alloc((size_t)n * mu * 8);
+    hipStream_t st = D->stream;
+    HIP_OK(hipMemcpyAsync(d_in.p, B, (size_t)n * mu * 8, hipMemcpyHostToDevice, st));
+    const unsigned nblk = (unsigned)(((long long)n * mu + 255) / 256);
+    if (f->whole) hipLaunchKernelGGL(hlu_permute_rows_kernel<double>, dim3(nblk), dim3(256), 0, st, d_in.as<double>(), d_cl.as<double>(), D->perm_t, n, mu, 1);
+    else HIP_OK(hipMemcpyAsync(d_cl.p, d_in.p, (size_t)n * mu * 8, hipMemcpyDeviceToDevice, st));
+    device_hlu_solve(f, trans, d_cl.p, n, mu, (void *)st);
+    if (f->whole) hipLaunchKernelGGL(hlu_permute_rows_kernel<double>, dim3(nblk), dim3(256), 0, st, d_cl.as<double>(), d_in.as<double>(), D->perm_t, n, mu, 0);
+    else HIP_OK(hipMemcpyAsync(d_in.p, d_cl.p, (size_t)n * mu * 8, hipMemcpyDeviceToDevice, st));
+    HIP_OK(hipMemcpyAsync(B, d_in.p, (size_t)n * mu * 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+}
+
 // ---- diagnostic entry: a plan executed by the device kernels on HOST arrays (uploaded, run, downloaded) -----------------------
 // The counterpart of oracle/hlu_exec.cpp's hluo_run: tests feed both the same arrays, window by window, and compare.
 extern "C" int htool_hlu_debug_execute(const htool_hlu_plan *plan_, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,
-                                       int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs);
+                                       int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs, double *scratch);
 extern "C" int htool_hlu_debug_execute(const htool_hlu_plan *plan_, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,
-                                       int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs) {
+                                       int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs, double *scratch) {
     API_BEGIN
     HM_CHECK(plan_ && plan_->plan, "htool_hlu_debug_execute: null plan");
     HM_CHECK(device_count() > 0, "no HIP device available for the hierarchical LU");
@@ -748,7 +880,7 @@ extern "C" int htool_hlu_debug_execute(const htool_hlu_plan *plan_, int first, i
     try {
         if (first >= 0) {
             HM_CHECK(last < (int)P->factor.size() && first <= last, "htool_hlu_debug_execute: no such window");
-            hlu_run_windows(f, first, last, st);
+            hlu_run_windows(f, first, last, st, scratch);
         } else {
             HM_CHECK(rhs != nullptr && ld_rhs >= P->n, "htool_hlu_debug_execute: a solve needs right-hand sides");
             hlu_upload_solves(f);

@@ -200,7 +200,11 @@ struct Emitter {
         t.kref = kref; t.kconst = kconst;
         t.y = ref(Y, T.offset[node]);
         t.y_ld = Y.ld;
-        const int lev = emit(t, Y.tr->dep_write(cell0[node], cell1[node]));
+        // (the number of columns is the rank of a leaf: it must be the one the consumers of the block will see)
+        int dep = Y.tr->dep_write(cell0[node], cell1[node]);
+        if (kref >= 0 && kref < (int)P.leaves.size()) dep = std::max(dep, dep_leaf_read(kref));
+        const int lev = emit(t, dep);
+        if (kref >= 0 && kref < (int)P.leaves.size()) note_leaf_read(kref, lev);
         Y.tr->note_write(cell0[node], cell1[node], lev);
     }
     // Y[rows of the output side] (+)= -+ op(leaf restricted to (it, is)) X[rows of the input side]
@@ -563,14 +567,17 @@ struct Emitter {
 
 } // namespace
 
-Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Params &prm) {
+Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Params &prm, int root) {
     const double t0 = wall_seconds();
     HM_CHECK(prm.cap_max <= 64 && prm.cap_min >= 8 && prm.cap_min <= prm.cap_max, "hierarchical LU: leaf capacities must lie in [8, 64]");
     std::unique_ptr<Plan> plan(new Plan);
     Plan &P = *plan;
     P.tree = &T;
     P.params = prm;
-    P.n = T.n_points;
+    HM_CHECK(root >= 0 && root < T.node_count(), "hierarchical LU: unknown root node");
+    P.root = root;
+    P.n = T.size[root];
+    P.pos0 = T.offset[root];
     Emitter E(T, P);
     const int nn = T.node_count();
     // cells: the cluster leaves in position order
@@ -637,7 +644,7 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
     P.diag_elems = de;
     E.next_slot = (int64_t)in.size();
     E.diag_bnode.assign(nn, -1);
-    E.build_bnode(0, 0, leaf_of);
+    E.build_bnode(root, root, leaf_of);
     {
         int64_t used = 0;
         for (const BNode &b : E.bn) used += b.leaf >= 0;
@@ -654,7 +661,7 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
     // window 0: every low-rank leaf is truncated once (ranks of the compression -> ranks of the arithmetic; norms)
     for (size_t i = 0; i < in.size(); i++) if (P.leaves[i].kind == 1) { E.dirty[i] = 1; E.ensure_final((int)i); }
     E.close_window();
-    E.lu(0);
+    E.lu(root);
     for (size_t i = 0; i < in.size(); i++) E.ensure_final((int)i);
     E.close_window();
     P.n_slots = E.next_slot;
@@ -665,13 +672,13 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
         for (Track &t : E.trD) t = Track();
         E.window_base = 1; E.max_level = 0; E.scratch_used = 0;
         Track rhs;
-        rhs.init(E.cell0[0], E.cell1[0] - E.cell0[0]);
+        rhs.init(E.cell0[root], E.cell1[root] - E.cell0[root]);
         Thin X;
-        X.base = 0; X.ld = -1; X.pos0 = 0; X.space = SP_RHS; X.tr = &rhs;
+        X.base = 0; X.ld = -1; X.pos0 = P.pos0; X.space = SP_RHS; X.tr = &rhs;
         int64_t keep[T_NTYPES];
         for (int q = 0; q < T_NTYPES; q++) keep[q] = P.counts[q];
-        if (pass == 0) { E.thin_solve_l(0, X, -2, 0); E.thin_solve_u(0, X, -2, 0); }
-        else { E.thin_solve_ut(0, X, -2, 0); E.thin_solve_lt(0, X, -2, 0); }
+        if (pass == 0) { E.thin_solve_l(root, X, -2, 0); E.thin_solve_u(root, X, -2, 0); }
+        else { E.thin_solve_ut(root, X, -2, 0); E.thin_solve_lt(root, X, -2, 0); }
         for (int q = 0; q < T_NTYPES; q++) P.counts[q] = keep[q];
         E.finish_program(E.cur, pass == 0 ? P.solve_n : P.solve_t);
     }

@@ -195,6 +195,7 @@ int64_t device_recompress(HMatrix &H, double eps);
 void device_clone(const HMatrix &src, HMatrix &dst);
 void device_leaf_panels(const HMatrix &H, int64_t leaf, void *A, void *B);
 int64_t device_leaf_panels_bulk(const HMatrix &H, int64_t n, const int64_t *ids, int64_t *offs, void *out);
+void device_unpack_leaves(const HMatrix &H, int64_t n, const int64_t *ids, const int64_t *u_offs, const int64_t *v_offs, void *d_arena); // (hierarchical LU: leaves into its own arena)
 int64_t device_resident_bytes(const HMatrix &H);
 double device_last_product_us(const HMatrix &H);
 int device_phase_times(const HMatrix &H, double *out4);

@@ -543,7 +543,23 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 py::gil_scoped_release nogil;
                 check(htool_hmatrix_to_dense_device(s.h, (void *)out_dev, ld, (void *)stream));
             }, "out_ptr"_a, "ld"_a, "stream"_a = 0)
-        .def("cholesky_factorization", [](H &s, char UPLO) { check(htool_hmatrix_cholesky_factorization(s.h, UPLO)); })
+        .def("cholesky_factorization", [](H &s, char UPLO) { py::gil_scoped_release nogil; check(htool_hmatrix_cholesky_factorization(s.h, UPLO)); })
+        .def("factorization_info", [](const H &s) {
+                int64_t v[17];
+                double sec[4];
+                check(htool_hmatrix_factorization_info(s.h, v, sec));
+                py::dict d;
+                static const char *kinds[] = {"none", "dense host", "dense device", "hierarchical"};
+                d["kind"] = kinds[v[0] < 0 || v[0] > 3 ? 0 : v[0]];
+                if (v[0] == 3) {
+                    static const char *names[] = {"unknowns", "leaves", "tasks", "launches", "windows", "factor_bytes", "scratch_bytes", "truncations_at_capacity", "truncations", "appended_columns",
+                                                  "dense_product_columns", "solve_tasks", "solve_launches", "rank_weight", "rows_plus_columns", "eps_e12"};
+                    for (int i = 0; i < 16; i++) d[names[i]] = v[1 + i];
+                    d["plan_s"] = sec[0]; d["unpack_s"] = sec[1]; d["factor_s"] = sec[2]; d["total_s"] = sec[3];
+                }
+                return d;
+            }, "What the last lu_factorization / cholesky_factorization left behind: kind = 'hierarchical' (device H-LU, the default), 'dense device', 'dense host' or 'none', with the "
+               "statistics of a hierarchical factorisation")
         .def("lu_solve", [](const H &s, char trans, const py::array_t<T, py::array::f_style> &input) {
                 if (input.ndim() != 1 && input.ndim() != 2) throw std::runtime_error("Wrong dimension for HMatrix-LU input");
                 py::array_t<T, py::array::f_style> result = input.ndim() == 1 ? py::array_t<T, py::array::f_style>(input.shape(0))
@@ -906,13 +922,14 @@ PYBIND11_MODULE(Htool, m) {
                 return py::make_tuple(t, b, g, scratch);
             }, "which"_a)
         .def("debug_execute", [](const PyHluPlan &s, int first, int last, py::array_t<double> factor, py::array_t<double> diag, py::array_t<int32_t> rank,
-                                 py::array_t<double> norm0, py::array_t<double> norm2, py::array_t<int64_t> counters, py::object rhs, long long ld_rhs, int nrhs) {
-                double *r = nullptr;
+                                 py::array_t<double> norm0, py::array_t<double> norm2, py::array_t<int64_t> counters, py::object rhs, long long ld_rhs, int nrhs, py::object scratch) {
+                double *r = nullptr, *sc = nullptr;
                 if (!rhs.is_none()) r = rhs.cast<py::array_t<double>>().mutable_data();
+                if (!scratch.is_none()) sc = scratch.cast<py::array_t<double>>().mutable_data();
                 py::gil_scoped_release nogil;
                 check(htool_hlu_debug_execute(s.p, first, last, factor.mutable_data(), diag.mutable_data(), rank.mutable_data(), norm0.mutable_data(), norm2.mutable_data(),
-                                              counters.mutable_data(), r, ld_rhs, nrhs));
-            }, "first"_a, "last"_a, "factor"_a, "diag"_a, "rank"_a, "norm0"_a, "norm2"_a, "counters"_a, "rhs"_a = py::none(), "ld_rhs"_a = 0, "nrhs"_a = 0)
+                                              counters.mutable_data(), r, ld_rhs, nrhs, sc));
+            }, "first"_a, "last"_a, "factor"_a, "diag"_a, "rank"_a, "norm0"_a, "norm2"_a, "counters"_a, "rhs"_a = py::none(), "ld_rhs"_a = 0, "nrhs"_a = 0, "scratch"_a = py::none())
         .def("tables", [](const PyHluPlan &s) {
                 const void *leaves, *diags;
                 int64_t info[3];

@@ -8,9 +8,9 @@ package's own restarted GMRES on GPU-resident vectors (krylov.py) with the H-mat
 Only the options the reference's tests use are parsed (tests/test_ddm_solver.py:550-558):
 -hpddm_krylov_method gmres, -hpddm_tol, -hpddm_max_it, -hpddm_gmres_restart, -hpddm_variant right.
 `facto_one_level()` sets up the one-level right preconditioner.  As in the reference it is the inverse of the rank's whole
-diagonal block `block_diagonal_hmatrix` (one-level Schwarz without overlap) -- applied through a DENSE device factorisation of
-that block (DenseBlockLU; the reference uses a hierarchical LU, which this engine does not have) while the dense copy fits the
-device; otherwise (or without that block) block-Jacobi from the DENSE DIAGONAL LEAVES of this rank's H-matrix:
+diagonal block `block_diagonal_hmatrix` (one-level Schwarz without overlap) -- applied through the HIERARCHICAL device LU of
+that block (BlockLU -> csrc/hlu_device.hip, round 4; a dense device factorisation for operators it does not cover);
+otherwise (or without that block) block-Jacobi from the DENSE DIAGONAL LEAVES of this rank's H-matrix:
 the leaves (t, t) of the cluster-tree leaves tile the diagonal; they are downloaded once, LU-factorised as one padded batch
 (library call).  GenEO coarse spaces are out of scope.
 """
@@ -173,24 +173,21 @@ class BlockJacobi:
         return sol.reshape(-1)[self.index]
 
 
-class DenseBlockLU:
+class BlockLU:
     """M^-1 = (the rank's whole diagonal block + shift I)^-1: what the reference's `facto_one_level()` applies (one-level Schwarz
-    without overlap: the H-LU of `block_diagonal_hmatrix`, example/use_ddm_solver.py:48-63).  Here the block is expanded to a dense
-    matrix ON THE DEVICE and factorised by the dense solver library (htool_hmatrix_lu_factorization_shifted, dense_device.hip) --
-    a dense fallback, not a hierarchical factorisation: it is used while the dense copy fits comfortably (62 500 unknowns, the
-    per-GPU block of the 500 000-point configuration on 8 GPUs, are 31 GB)."""
+    without overlap: the H-LU of `block_diagonal_hmatrix`, example/use_ddm_solver.py:48-63).  The block is factorised
+    HIERARCHICALLY on the device (htool_hmatrix_lu_factorization_shifted -> csrc/hlu_device.hip; round 4) and applied by the
+    factorisation's two leaf sweeps on the Krylov loop's device vectors.  Operators the hierarchical factorisation does not
+    cover (complex, tolerances below 1e-7) get a dense copy factorised by the dense solver library instead (dense_device.hip),
+    which raises when that copy does not fit the device."""
 
     def __init__(self, block_hmatrix, shift=0.0):
         n, m = block_hmatrix.shape
         if n != m:
-            raise RuntimeError("DenseBlockLU: the diagonal block is not square")
+            raise RuntimeError("BlockLU: the diagonal block is not square")
         self.H, self.n = block_hmatrix, n
-        block_hmatrix.lu_factorization_shifted(float(shift))  # (the device path of the dense fallback, whatever the size: the solve must be on the device)
-
-    @staticmethod
-    def fits(n, is_complex, fraction=0.35):
-        free, _total = torch.cuda.mem_get_info()
-        return n * n * (16 if is_complex else 8) * 1.1 <= fraction * free
+        block_hmatrix.lu_factorization_shifted(float(shift))
+        self.kind = block_hmatrix.factorization_info()["kind"]
 
     def __call__(self, v):
         """v: (size,) or (mu, size), this rank's slice in cluster numbering."""
@@ -199,6 +196,9 @@ class DenseBlockLU:
         ldb = self.n if out.dim() == 1 else out.stride(0)
         self.H.factor_solve_device(1, "N", out.data_ptr(), max(ldb, 1), mu, torch.cuda.current_stream().cuda_stream)
         return out
+
+
+DenseBlockLU = BlockLU  # (the name of round 3, when the factorisation was dense only)
 
 
 class Solver:
@@ -232,19 +232,20 @@ class Solver:
             self._perm = np.arange(self.op.H.shape[1])
 
     def facto_one_level(self):
-        """One-level preconditioner (src/htool/solver/solver.hpp: facto_one_level).  With the rank's `block_diagonal_hmatrix` at hand
-        and its dense copy fitting the device: the inverse of that whole block, as the reference (DenseBlockLU: a dense device
-        factorisation standing in for the H-LU).  Otherwise block-Jacobi on the dense diagonal leaves of the local rows."""
+        """One-level preconditioner (src/htool/solver/solver.hpp: facto_one_level).  With the rank's `block_diagonal_hmatrix` at hand:
+        the inverse of that whole block, as the reference, through its hierarchical LU on the device (BlockLU).  Without it, or when
+        the block cannot be factorised: block-Jacobi on the dense diagonal leaves of the local rows."""
         import logging
 
         blk = self._block
-        if blk is not None and blk.shape == (self.op.size, self.op.size) and DenseBlockLU.fits(self.op.size, torch.zeros(0, dtype=self._dtype()).is_complex()):
-            self._precond = DenseBlockLU(blk, self.op.shift)
-            self._precond_name = "one-level: dense device LU of block_diagonal_hmatrix"
-            return
-        if blk is not None:
-            logging.getLogger("Htool").warning("facto_one_level: the dense copy of block_diagonal_hmatrix (%d unknowns) does not fit the device comfortably -- block-Jacobi on the "
-                                               "dense diagonal leaves instead (hierarchical LU is not part of this engine)", self.op.size)
+        if blk is not None and blk.shape == (self.op.size, self.op.size):
+            try:
+                self._precond = BlockLU(blk, self.op.shift)
+                self._precond_name = "one-level: %s LU of block_diagonal_hmatrix" % {"hierarchical": "hierarchical device", "dense device": "dense device"}.get(self._precond.kind, self._precond.kind)
+                return
+            except RuntimeError as e:  # (neither the hierarchical factorisation nor a dense copy: say so, precondition with less)
+                logging.getLogger("Htool").warning("facto_one_level: block_diagonal_hmatrix (%d unknowns) could not be factorised (%s) -- block-Jacobi on the dense diagonal "
+                                                   "leaves instead", self.op.size, e)
         self._precond = BlockJacobi(self.op.H, self.op.offset, self.op.size, self.op.shift)
         self._precond_name = "block-jacobi (dense diagonal leaves)"
 
@@ -312,8 +313,9 @@ class DDMSolverBuilder:
 
     Only the two-argument form of the reference (utility.hpp:14) is on the HIP path.  The reference factorises
     `block_diagonal_hmatrix` hierarchically in `facto_one_level()` (one-level Schwarz without overlap = block-Jacobi with the
-    rank's whole diagonal block); here `facto_one_level()` factorises a DENSE copy of it on the device (DenseBlockLU) while that
-    fits, and falls back -- with a WARNING -- to block-Jacobi on the dense diagonal leaves of the rank's rows otherwise.  The
+    rank's whole diagonal block); so does `facto_one_level()` here (BlockLU: the hierarchical LU on the device, round 4; a dense
+    device factorisation for operators it does not cover), falling back -- with a WARNING -- to block-Jacobi on the dense diagonal
+    leaves of the rank's rows when neither works.  The
     overlapping forms (utility.hpp:16-40: subdomain numberings, neighbours, intersections) need HPDDM's Schwarz machinery and
     are refused."""
 

@@ -378,6 +378,12 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
  * htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
  * each, struct hm::hlu::Task), launch buckets and target runs of one window of the factorisation (which >= 0) or of the
  * solves (-1: 'N', -2: 'T'); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
+/* what htool_hmatrix_lu_factorization / _cholesky_factorization left behind: out17[0] = 0 nothing, 1 dense on the host, 2 dense on
+ * the device, 3 hierarchical; for 3, out17[1..16] = unknowns, leaves, tasks, launches, windows, bytes of the factors, bytes of scratch,
+ * truncations cut at a leaf's capacity, truncations, appended columns, columns out of dense-leaf products, tasks and launches of one
+ * solve, sum of rank x (rows + columns) over the low-rank leaves, sum of (rows + columns), tolerance x 1e12; seconds4 = plan, leaves
+ * into the factor arena, factorisation, total. */
+int htool_hmatrix_factorization_info(const htool_hmatrix *h, int64_t *out17, double *seconds4);
 typedef struct htool_hlu_plan htool_hlu_plan;
 int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int32_t *rects5, double epsilon, int cap_min, int cap_max, double cap_factor,
                           int64_t window_scratch_elems, int64_t window_tasks, htool_hlu_plan **out);
@@ -388,9 +394,9 @@ int htool_hlu_plan_tables(const htool_hlu_plan *plan, const void **leaves, const
 void htool_hlu_plan_free(htool_hlu_plan *plan);
 /* diagnostic: windows first..last of the plan's factorisation (first >= 0), or one of its solves (first = -1 'N', -2 'T') executed by
  * the DEVICE kernels on host arrays laid out as the plan says (uploaded, run, downloaded) -- the counterpart of the CPU checker
- * oracle/hlu_exec.cpp, which tests feed the same arrays.  counters: 8 values. */
+ * oracle/hlu_exec.cpp, which tests feed the same arrays.  counters: 8 values; scratch (may be NULL): the window's scratch space, in and out. */
 int htool_hlu_debug_execute(const htool_hlu_plan *plan, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,
-                            int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs);
+                            int64_t *counters, double *rhs, int64_t ld_rhs, int nrhs, double *scratch);
 
 #ifdef __cplusplus
 }

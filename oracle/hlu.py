@@ -81,8 +81,8 @@ class HostLU:
             for w in range(I["windows"]):
                 self.run_window(w, shuffle)
 
-    def run_window(self, w, shuffle=0):
-        self._run(w, None, 0, shuffle)
+    def run_window(self, w, shuffle=0, max_buckets=None):
+        self._run(w, None, 0, shuffle, max_buckets)
 
     def leaf_dense(self, i):
         """The block a leaf stands for now (dense copy), from the factor arena."""
@@ -93,10 +93,13 @@ class HostLU:
         r = int(self.rank[i])
         return self.factor[L["u"]:L["u"] + m * r].reshape(r, m).T @ self.factor[L["v"]:L["v"] + n * r].reshape(r, n)
 
-    def _run(self, which, rhs, nrhs, shuffle=0):
+    def _run(self, which, rhs, nrhs, shuffle=0, max_buckets=None):
         t, b, g, _ = self.plan.program(which)
         t, b, g = np.ascontiguousarray(t), np.ascontiguousarray(b), np.ascontiguousarray(g)
-        lib().hluo_run(_p(t), t.shape[0], _p(b), b.shape[0], _p(g), _p(self.leaves), _p(self.diags), _p(self.factor), _p(self.diag), _p(self.scratch),
+        nb = b.shape[0] if max_buckets is None else min(b.shape[0], max_buckets)
+        if which >= 0:
+            self.scratch[:] = np.nan  # (a window must not read scratch it has not written)
+        lib().hluo_run(_p(t), t.shape[0], _p(b), nb, _p(g), _p(self.leaves), _p(self.diags), _p(self.factor), _p(self.diag), _p(self.scratch),
                        _p(rhs), 0 if rhs is None else self.info["n"], nrhs,
                        _p(self.rank), _p(self.norm0), _p(self.norm2), self.eps, _p(self.counters), shuffle)
 

@@ -69,7 +69,7 @@ void jacobi(double *M, double *J, int n, int ld) {
     }
 }
 
-int keep_max(const Leaf &L) { return L.cap - std::max(4, L.cap / 4); }
+int keep_max(const Leaf &L) { return L.cap - std::max(4, L.cap / 6); }
 
 // U V^T (K columns) -> the truncated form: balanced Gram matrices, their eigenvectors, SVD of the small core
 void recompress(State &S, int l) {

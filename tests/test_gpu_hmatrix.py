@@ -61,8 +61,9 @@ def test_hmatrix_reference_case(built, oracle, symmetry, custom_svd):
     assert np.linalg.norm(Y - copy_hmatrix @ X) < 1e-10
 
     if symmetry != "N":
-        # H-LU / H-Cholesky solves (tests/test_hmatrix.py:98-128); served by the dense host fallback
+        # H-LU / H-Cholesky solves (tests/test_hmatrix.py:98-128): the hierarchical factorisation on the device (round 4)
         copy_hmatrix.lu_factorization()
+        assert copy_hmatrix.factorization_info()["kind"] == "hierarchical"
         x_ref = np.ones(nb_cols)
         x_lu = copy_hmatrix.lu_solve("N", hmatrix * x_ref)
         assert np.linalg.norm(x_lu - x_ref) / np.linalg.norm(x_ref) < epsilon

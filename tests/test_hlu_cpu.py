@@ -24,7 +24,7 @@ def make_case(n, leaf, eps, eta=10.0, children=2):
 def test_plan_executed_on_the_cpu_solves_the_system(n, leaf, eta, children):
     eps, eps_lu = 1e-3, 1e-4
     H, cl = make_case(n, leaf, eps, eta, children)
-    plan = Htool.HLUPlan(cl, H.leaves, eps_lu, cap_factor=2 * np.log(eps_lu) / np.log(eps))
+    plan = Htool.HLUPlan(cl, H.leaves, eps_lu, cap_factor=2.5 * np.log(eps_lu) / np.log(eps))
     lu = ohlu.HostLU(plan, H.leaf_data, eps_lu)
     A = H.to_dense()  # cluster numbering
     x_ref = np.ones(n)
