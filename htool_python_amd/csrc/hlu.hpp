@@ -78,7 +78,8 @@ struct Program {
 
 struct Params {
     double eps = 1e-3;   // relative truncation tolerance of the low-rank arithmetic
-    int cap_min = 16, cap_max = 64, cap_extra = 8; // capacity of a leaf: clamp(ceil(cap_factor rank) + cap_extra, cap_min, cap_max)
+    int cap_min = 64, cap_max = 64, cap_extra = 8; // capacity of a leaf: clamp(ceil(cap_factor rank) + cap_extra, cap_min, cap_max); by default every leaf gets the 64 columns the
+                                                   // truncation kernel handles on chip: the room left above its rank is what it can take in before it is truncated again
     double cap_factor = 2.5;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
     int64_t window_scratch_elems = (int64_t)1 << 29; // a window of the task stream may hold this much scratch (4 GB of doubles)
     int64_t window_tasks = (int64_t)1 << 23;

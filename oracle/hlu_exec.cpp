@@ -44,34 +44,47 @@ inline double *at(const State &S, int64_t ref) { return S.space[(int)(ref >> 60)
 inline int cols_of(const State &S, const Task &t) { return t.kref >= 0 ? S.rank[t.kref] : t.kref == -1 ? t.kconst : S.nrhs; }
 inline int64_t ld_of(const State &S, int64_t ref, int ld) { return (ref >> 60) == 3 ? S.ld_rhs : ld; }
 
-// one-sided Jacobi on the columns of M (n x n, row-major stride ld): M <- M J, J accumulated (starts as the identity)
-void jacobi(double *M, double *J, int n, int ld) {
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) J[i * ld + j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; sweep++) {
-        bool rotated = false;
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
-                double al = 0, be = 0, ga = 0;
-                for (int i = 0; i < n; i++) { al += M[i * ld + p] * M[i * ld + p]; be += M[i * ld + q] * M[i * ld + q]; ga += M[i * ld + p] * M[i * ld + q]; }
-                if (ga == 0.0 || std::fabs(ga) <= 1e-15 * std::sqrt(al * be)) continue;
-                rotated = true;
-                const double zeta = (be - al) / (2 * ga);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
-                const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
-                for (int i = 0; i < n; i++) {
-                    double x = M[i * ld + p], y = M[i * ld + q];
-                    M[i * ld + p] = cs * x - sn * y; M[i * ld + q] = sn * x + cs * y;
-                    x = J[i * ld + p]; y = J[i * ld + q];
-                    J[i * ld + p] = cs * x - sn * y; J[i * ld + q] = sn * x + cs * y;
-                }
-            }
-        if (!rotated) break;
+int keep_max(const Leaf &L) { return L.cap - std::max(4, L.cap / 8); }
+
+// Cholesky factor with diagonal pivoting of a Gram matrix G (K x K, destroyed): rows R[j][:] (all K columns, ORIGINAL column order)
+// with G = R^T R up to what is left; piv[j] = column chosen at step j.  Stops when the largest remaining diagonal entry is below
+// 1e-14 of the first one (numerical rank), or -- stop2 >= 0 -- as soon as the remaining trace is at most stop2 times the trace
+// (the Frobenius norm of what the chosen columns do not span), or after max_steps.  Returns the number of steps; *left = remaining trace.
+int pivoted_cholesky(double *G, double *R, int *piv, int K, int ld, double stop2, int max_steps, double *trace0, double *left) {
+    double dmax0 = 0, tr0 = 0;
+    for (int i = 0; i < K; i++) { dmax0 = std::max(dmax0, G[i * ld + i]); tr0 += std::max(G[i * ld + i], 0.0); }
+    if (trace0) *trace0 = tr0;
+    int r = 0;
+    double tr = tr0;
+    for (; r < K && r < max_steps; r++) {
+        int p = 0;
+        double best = -1;
+        tr = 0;
+        for (int i = 0; i < K; i++) { tr += std::max(G[i * ld + i], 0.0); if (G[i * ld + i] > best) { best = G[i * ld + i]; p = i; } }
+        if (!(best > 1e-14 * dmax0) || !(best > 0)) break;
+        if (stop2 >= 0 && tr <= stop2 * tr0) break;
+        piv[r] = p;
+        const double inv = 1.0 / std::sqrt(best);
+        for (int i = 0; i < K; i++) R[r * ld + i] = G[p * ld + i] * inv;
+        for (int a = 0; a < K; a++) for (int b = 0; b < K; b++) G[a * ld + b] -= R[r * ld + a] * R[r * ld + b];
+        G[p * ld + p] = 0.0; // (exactly: the column is used up)
+        tr = 0;
+        for (int i = 0; i < K; i++) tr += std::max(G[i * ld + i], 0.0);
     }
+    if (left) *left = tr;
+    return r;
 }
 
-int keep_max(const Leaf &L) { return L.cap - std::max(4, L.cap / 6); }
-
-// U V^T (K columns) -> the truncated form: balanced Gram matrices, their eigenvectors, SVD of the small core
+// U V^T (K columns) -> the truncated form, without any SVD: rank-revealing Cholesky factorisations of small Gram matrices.
+// With the columns balanced (u_a d_a, v_a / d_a: U^, V^) and G_v = R_v^T R_v factorised with diagonal pivoting (rank rv),
+// V^ = Q_v R_v with Q_v = V^[:, piv_v] R_v[:, piv_v]^-1 orthonormal, so U^ V^^T = B Q_v^T with B = U^ R_v^T (m x rv) and
+// |U V^T|_F = |B|_F.  The Gram matrix of B is M = R_v G_u R_v^T (rv x rv, formed from the small matrices); its Cholesky
+// factorisation with diagonal pivoting M = R_B^T R_B picks columns of B one at a time, and the trace of what is left IS the squared
+// Frobenius distance of B to the span of the picked columns: the factorisation stops when that is below eps^2 |B|_F^2 (r' steps).
+// Then B ~ Q_B R_B with Q_B = B[:, piv_B] R_B[:, piv_B]^-1, and the leaf becomes Q_B (Q_v R_B^T)^T:
+//   U' = U T_u,  T_u = D R_v^T[:, piv_B] R_B[:, piv_B]^-1  (K x r');      V' = V T_v,  T_v[piv_v, :] = D^-1 R_v[:, piv_v]^-1 R_B^T.
+// A truncation by column selection instead of singular vectors: the same Frobenius bound, a rank that can be a little above the
+// optimal one, a few dozen microseconds on the device instead of the millisecond of a Jacobi SVD.
 void recompress(State &S, int l) {
     const Leaf &L = S.leaves[l];
     const int K = S.rank[l], m = L.m, n = L.n;
@@ -79,7 +92,8 @@ void recompress(State &S, int l) {
     S.counters[1]++;
     if (K == 0) { S.norm2[l] = 0; if (S.norm0[l] < 0) S.norm0[l] = 0; return; }
     const int ld = K;
-    std::vector<double> Gu((size_t)K * K), Gv((size_t)K * K), Eu((size_t)K * K), Ev((size_t)K * K), d(K), su(K), sv(K);
+    std::vector<double> Gu((size_t)K * K), Gv((size_t)K * K), Rv((size_t)K * K), T1((size_t)K * K), M((size_t)K * K), RB((size_t)K * K), d(K);
+    std::vector<int> pv(K), pb(K);
     for (int a = 0; a < K; a++)
         for (int b = a; b < K; b++) {
             double s = 0;
@@ -89,7 +103,6 @@ void recompress(State &S, int l) {
             for (int i = 0; i < n; i++) s += V[(int64_t)a * n + i] * V[(int64_t)b * n + i];
             Gv[a * ld + b] = Gv[b * ld + a] = s;
         }
-    // balance: column a of U times d_a, of V divided by it (null columns drop out)
     for (int a = 0; a < K; a++) {
         const double gu = Gu[a * ld + a], gv = Gv[a * ld + a];
         d[a] = (gu > 0 && gv > 0) ? std::sqrt(std::sqrt(gv / gu)) : 0.0;
@@ -100,69 +113,53 @@ void recompress(State &S, int l) {
             Gu[a * ld + b] *= dd;
             Gv[a * ld + b] = dd > 0 ? Gv[a * ld + b] / dd : 0.0;
         }
-    jacobi(Gu.data(), Eu.data(), K, ld);
-    jacobi(Gv.data(), Ev.data(), K, ld);
-    double lu_max = 0, lv_max = 0;
-    for (int j = 0; j < K; j++) {
-        double a = 0, b = 0;
-        for (int i = 0; i < K; i++) { a += Gu[i * ld + j] * Gu[i * ld + j]; b += Gv[i * ld + j] * Gv[i * ld + j]; }
-        su[j] = std::sqrt(std::sqrt(a)); sv[j] = std::sqrt(std::sqrt(b)); // eigenvalue = norm of the column; singular value = its root
-        lu_max = std::max(lu_max, su[j]); lv_max = std::max(lv_max, sv[j]);
-    }
-    for (int j = 0; j < K; j++) { if (!(su[j] > 1e-7 * lu_max)) su[j] = 0; if (!(sv[j] > 1e-7 * lv_max)) sv[j] = 0; }
-    // core C = S_u E_u^T E_v S_v (over Gu), its SVD C J = W (J over Gv)
-    for (int i = 0; i < K; i++)
-        for (int j = 0; j < K; j++) {
+    const int rv = pivoted_cholesky(Gv.data(), Rv.data(), pv.data(), K, ld, -1.0, K, nullptr, nullptr);
+    if (rv == 0) { S.rank[l] = 0; S.norm2[l] = 0; if (S.norm0[l] < 0) S.norm0[l] = 0; return; }
+    for (int a = 0; a < K; a++) // T1 = G_u R_v^T (K x rv)
+        for (int b = 0; b < rv; b++) {
             double s = 0;
-            for (int a = 0; a < K; a++) s += Eu[a * ld + i] * Ev[a * ld + j];
-            Gu[i * ld + j] = su[i] * s * sv[j];
+            for (int i = 0; i < K; i++) s += Gu[a * ld + i] * Rv[b * ld + i];
+            T1[a * ld + b] = s;
         }
-    jacobi(Gu.data(), Gv.data(), K, ld);
-    std::vector<double> sig(K);
-    std::vector<int> ord(K);
-    double tot = 0;
-    for (int j = 0; j < K; j++) {
-        double s = 0;
-        for (int i = 0; i < K; i++) s += Gu[i * ld + j] * Gu[i * ld + j];
-        sig[j] = s; tot += s; ord[j] = j;
-    }
-    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sig[x] > sig[y]; });
-    int newr = K;
-    double tail = 0;
-    for (int k = K - 1; k >= 0; k--) {
-        if (tail + sig[ord[k]] <= S.eps * S.eps * tot) { tail += sig[ord[k]]; newr = k; }
-        else break;
-    }
-    if (newr > keep_max(L)) { newr = keep_max(L); S.counters[0]++; }
-    double kept = 0;
-    for (int c = 0; c < newr; c++) kept += sig[ord[c]];
-    S.norm2[l] = kept;
-    if (S.norm0[l] < 0) S.norm0[l] = kept;
-    // T_u = D E_u S_u^-1 W[:, sel] (over Eu, row by row), T_v = D^-1 E_v S_v^-1 J[:, sel] (over Ev)
-    std::vector<double> row(K), out(K);
+    for (int a = 0; a < rv; a++) // M = R_v T1 (rv x rv), symmetrised
+        for (int b = a; b < rv; b++) {
+            double s = 0;
+            for (int i = 0; i < K; i++) s += Rv[a * ld + i] * T1[i * ld + b];
+            M[a * ld + b] = M[b * ld + a] = s;
+        }
+    double tot = 0, left = 0;
+    int newr = pivoted_cholesky(M.data(), RB.data(), pb.data(), rv, ld, S.eps * S.eps, keep_max(L), &tot, &left);
+    if (newr == keep_max(L) && left > S.eps * S.eps * tot) S.counters[0]++;
+    S.norm2[l] = tot - left;
+    if (S.norm0[l] < 0) S.norm0[l] = tot - left;
+    // T_u: row a = d_a * (R_v[piv_B, a])^T R_B11^-1, R_B11[j][c] = RB[j][pb[c]] upper triangular in pivot order
+    std::vector<double> Tu((size_t)K * std::max(newr, 1), 0.0), Tv((size_t)K * std::max(newr, 1), 0.0), y(K);
     for (int a = 0; a < K; a++) {
-        for (int i = 0; i < K; i++) row[i] = Eu[a * ld + i];
         for (int c = 0; c < newr; c++) {
-            double s = 0;
-            for (int i = 0; i < K; i++) if (su[i] > 0) s += row[i] / su[i] * Gu[i * ld + ord[c]];
-            out[c] = d[a] * s;
+            double s = Rv[pb[c] * ld + a];
+            for (int j = 0; j < c; j++) s -= y[j] * RB[j * ld + pb[c]];
+            y[c] = s / RB[c * ld + pb[c]];
         }
-        for (int c = 0; c < newr; c++) Eu[a * ld + c] = out[c];
-        for (int i = 0; i < K; i++) row[i] = Ev[a * ld + i];
-        for (int c = 0; c < newr; c++) {
-            double s = 0;
-            for (int i = 0; i < K; i++) if (sv[i] > 0) s += row[i] / sv[i] * Gv[i * ld + ord[c]];
-            out[c] = d[a] > 0 ? s / d[a] : 0.0;
-        }
-        for (int c = 0; c < newr; c++) Ev[a * ld + c] = out[c];
+        for (int c = 0; c < newr; c++) Tu[(size_t)a * newr + c] = d[a] * y[c];
     }
+    // T_v[pv[b], c] = (1 / d) * (R_v11^-1 R_B^T)[b, c], R_v11[a][b] = Rv[a][pv[b]] upper triangular in pivot order
+    for (int c = 0; c < newr; c++) {
+        for (int a = 0; a < rv; a++) y[a] = RB[c * ld + a];
+        for (int a = rv - 1; a >= 0; a--) {
+            double s = y[a];
+            for (int b = a + 1; b < rv; b++) s -= Rv[a * ld + pv[b]] * y[b];
+            y[a] = s / Rv[a * ld + pv[a]];
+        }
+        for (int b = 0; b < rv; b++) Tv[(size_t)pv[b] * newr + c] = y[b] / d[pv[b]];
+    }
+    std::vector<double> row(K);
     for (int i = 0; i < m; i++) {
         for (int k = 0; k < K; k++) row[k] = U[(int64_t)k * m + i];
-        for (int c = 0; c < newr; c++) { double s = 0; for (int k = 0; k < K; k++) s += row[k] * Eu[k * ld + c]; U[(int64_t)c * m + i] = s; }
+        for (int c = 0; c < newr; c++) { double s = 0; for (int k = 0; k < K; k++) s += row[k] * Tu[(size_t)k * newr + c]; U[(int64_t)c * m + i] = s; }
     }
     for (int i = 0; i < n; i++) {
         for (int k = 0; k < K; k++) row[k] = V[(int64_t)k * n + i];
-        for (int c = 0; c < newr; c++) { double s = 0; for (int k = 0; k < K; k++) s += row[k] * Ev[k * ld + c]; V[(int64_t)c * n + i] = s; }
+        for (int c = 0; c < newr; c++) { double s = 0; for (int b = 0; b < rv; b++) s += row[pv[b]] * Tv[(size_t)pv[b] * newr + c]; V[(int64_t)c * n + i] = s; }
     }
     S.rank[l] = newr;
 }
