@@ -38,7 +38,6 @@ int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int
     API_BEGIN
     HM_CHECK(root && rects5 && out, "htool_hlu_plan_create: null argument");
     const ClusterHandle *h = reinterpret_cast<const ClusterHandle *>(root);
-    HM_CHECK(h->node == 0, "htool_hlu_plan_create: needs the root cluster");
     hlu::Params P;
     if (epsilon > 0) P.eps = epsilon;
     if (cap_min > 0) P.cap_min = cap_min;
@@ -48,7 +47,7 @@ int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int
     if (window_tasks > 0) P.window_tasks = window_tasks;
     std::vector<hlu::LeafIn> in = hlu::leaves_from_rects(*h->tree, n_leaves, rects5);
     htool_hlu_plan *p = new htool_hlu_plan;
-    try { p->plan = hlu::make_plan(*h->tree, in, P); } catch (...) { delete p; throw; }
+    try { p->plan = hlu::make_plan(*h->tree, in, P, h->node); } catch (...) { delete p; throw; }
     *out = p;
     API_END
 }

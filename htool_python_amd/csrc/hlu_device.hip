@@ -915,7 +915,9 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
     if (f->n == 0 || mu == 0) return;
     HIP_OK(hipSetDevice(f->device));
     const Ctx c = f->ctx(nullptr, (double *)B_dev, ldb, mu);
-    run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, stream ? (hipStream_t)stream : f->stream);
+    // (the caller's stream as it is: NULL is the legacy default stream, which orders this against the caller's other default-stream work and
+    // against every blocking stream -- substituting the operator's own stream here would let a product on ANOTHER handle's stream overtake it)
+    run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, (hipStream_t)stream);
 }
 
 // ---- the factorisation of an operator -----------------------------------------------------------------------------------------

@@ -899,7 +899,7 @@ PYBIND11_MODULE(Htool, m) {
                  pl->owner = c.owner;
                  {
                      py::gil_scoped_release nogil;
-                     check(htool_hlu_plan_create(c.owner->root, rects5.shape(0), rects5.data(), epsilon, cap_min, cap_max, cap_factor, window_scratch_elems, window_tasks, &pl->p));
+                     check(htool_hlu_plan_create(c.node, rects5.shape(0), rects5.data(), epsilon, cap_min, cap_max, cap_factor, window_scratch_elems, window_tasks, &pl->p));
                  }
                  return pl;
              }), "cluster"_a, "rects"_a, "epsilon"_a = 1e-3, "cap_min"_a = 0, "cap_max"_a = 0, "window_scratch_elems"_a = 0, "window_tasks"_a = 0, "cap_factor"_a = 0.0)
