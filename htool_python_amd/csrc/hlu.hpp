@@ -58,7 +58,7 @@ struct Leaf { // 48 bytes
     int32_t t_off, m, s_off, n;
     int32_t kind; // 0 dense, 1 low rank
     int32_t cap;  // low rank: columns of room in U and V
-    int64_t u, v; // element offsets in the factor arena: dense D (m x n, ld m) at u;  low rank U (m x cap, ld m) at u, V (n x cap, ld n) at v
+    int64_t u, v; // space-tagged element offsets (the factor arena for the operator's leaves): dense D (m x n, ld m) at u;  low rank U (m x cap, ld m) at u, V (n x cap, ld n) at v
     int32_t diag; // dense (t, t): its record in the diagonal table, else -1
     int32_t rank0;
 };
@@ -83,6 +83,8 @@ struct Params {
     double cap_factor = 2.5;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
     int64_t window_scratch_elems = (int64_t)1 << 29; // a window of the task stream may hold this much scratch (4 GB of doubles)
     int64_t window_tasks = (int64_t)1 << 23;
+    int split_min = 12, split_part = 8, split_max_parts = 16; // a run of more than split_min updates of one low-rank leaf in one launch is dealt out to
+                                                              // up to split_max_parts workgroups (>= split_part updates each), each with a stage block of its own
 };
 
 struct Plan {
@@ -90,7 +92,9 @@ struct Plan {
     Params params;
     int root = 0;  // cluster node the operator is built on (the root, or a partition: the diagonal block of a rank)
     int n = 0, pos0 = 0; // its size and first position: row i of a right-hand side is cluster position pos0 + i
-    std::vector<Leaf> leaves;
+    std::vector<Leaf> leaves;      // the leaves of the operator first (n_real_leaves), then the STAGE blocks of split update runs: low-rank
+                                   // blocks in the scratch space (u / v are space-tagged references) that a part of a run accumulates into
+    int64_t n_real_leaves = 0;
     std::vector<Diag> diags;
     int64_t factor_elems = 0, diag_elems = 0, scratch_elems = 0; // arena sizes (elements)
     int64_t n_slots = 0;                                          // rank slots: leaves first, then the outputs of DDPROD tasks

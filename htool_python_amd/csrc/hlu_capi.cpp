@@ -62,7 +62,7 @@ int htool_hlu_plan_info(const htool_hlu_plan *p, int64_t *out, int n_out) {
     int64_t v[23];
     int64_t tasks = 0, launches = 0, levels = 0;
     for (const hlu::Program &w : P.factor) { tasks += (int64_t)w.tasks.size(); launches += (int64_t)w.buckets.size(); levels += w.n_levels; }
-    v[0] = P.n; v[1] = (int64_t)P.leaves.size(); v[2] = (int64_t)P.diags.size(); v[3] = P.factor_elems; v[4] = P.diag_elems; v[5] = P.scratch_elems;
+    v[0] = P.n; v[1] = P.n_real_leaves; v[2] = (int64_t)P.diags.size(); v[3] = P.factor_elems; v[4] = P.diag_elems; v[5] = P.scratch_elems;
     v[6] = P.n_slots; v[7] = (int64_t)P.factor.size(); v[8] = tasks; v[9] = launches; v[10] = levels;
     v[11] = (int64_t)P.solve_n.tasks.size(); v[12] = (int64_t)P.solve_n.buckets.size(); v[13] = P.solve_n.n_levels;
     v[14] = (int64_t)(P.plan_seconds * 1e6); v[15] = (int64_t)P.solve_t.tasks.size();
@@ -89,6 +89,7 @@ int htool_hlu_plan_program(const htool_hlu_plan *p, int which, const void **task
     API_END
 }
 
+/* leaves: one 48-byte record per rank slot (the operator's leaves first: htool_hlu_plan_info's out[1] of them) */
 int htool_hlu_plan_tables(const htool_hlu_plan *p, const void **leaves, const void **diags) {
     API_BEGIN
     HM_CHECK(p && p->plan, "htool_hlu_plan_tables: null argument");

@@ -230,7 +230,7 @@ __device__ int pchol_lds(double *G, double *R, int *piv, int K, int KS, double s
 __device__ void recompress(const Ctx &c, int l, const Leaf &L, double *sm, int Kc) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = c.rank[l], m = L.m, n = L.n, KS = Kc + 1;
-    double *U = c.space[0] + L.u, *V = c.space[0] + L.v;
+    double *U = at(c, L.u), *V = at(c, L.v);
     double *Gu = sm, *Gv = Gu + Kc * KS, *Rv = Gv + Kc * KS, *Mm = Rv + Kc * KS;
     double *T1 = Gv, *RB = Gv, *Tu = Gu, *Tv = Mm; // (what lives where once its predecessor is dead)
     double *d = Mm + Kc * KS, *s_red = d + Kc;
@@ -444,11 +444,11 @@ __global__ __launch_bounds__(256) void hlu_update_kernel(Ctx c, const Task *task
         const bool xt = t.flags & F_XT, zt = t.flags & F_YT;
         const double alpha = (t.flags & F_SUB) ? -1.0 : 1.0;
         if (L.kind == 0) {
-            double *D = c.space[0] + L.u + t.r0 + (long long)t.c0 * L.m;
+            double *D = at(c, L.u) + t.r0 + (long long)t.c0 * L.m;
             wg_gemm_nt(D, L.m, t.m, t.n, k, alpha, X, xt ? t.x_ld : 1, xt ? 1 : t.x_ld, Z, zt ? t.y_ld : 1, zt ? 1 : t.y_ld, sm);
             continue;
         }
-        double *U = c.space[0] + L.u, *V = c.space[0] + L.v;
+        double *U = at(c, L.u), *V = at(c, L.v);
         int done = 0;
         while (done < k) {
             int fill = c.rank[t.leaf];
@@ -1010,13 +1010,13 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
     int64_t tasks = 0, launches = 0, rank_sum = 0, lr_rows = 0;
     for (const Program &w : P.factor) { tasks += (int64_t)w.tasks.size(); launches += (int64_t)w.buckets.size(); }
     {
-        std::vector<int> r(P.leaves.size());
+        std::vector<int> r((size_t)P.n_real_leaves);
         HIP_OK(hipMemcpy(r.data(), f->rank, r.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < r.size(); i++) if (P.leaves[i].kind == 1) { rank_sum += (int64_t)r[i] * (P.leaves[i].m + P.leaves[i].n); lr_rows += P.leaves[i].m + P.leaves[i].n; }
     }
     f->seconds[3] = wall_seconds() - t_begin;
     int64_t *s = f->stats;
-    s[0] = P.n; s[1] = (int64_t)P.leaves.size(); s[2] = tasks; s[3] = launches; s[4] = (int64_t)P.factor.size();
+    s[0] = P.n; s[1] = P.n_real_leaves; s[2] = tasks; s[3] = launches; s[4] = (int64_t)P.factor.size();
     s[5] = (P.factor_elems + P.diag_elems) * 8; s[6] = P.scratch_elems * 8; s[7] = counters[0]; s[8] = counters[1]; s[9] = counters[2]; s[10] = counters[3];
     s[11] = (int64_t)P.solve_n.tasks.size(); s[12] = (int64_t)P.solve_n.buckets.size(); s[13] = rank_sum; s[14] = lr_rows; s[15] = (int64_t)(prm.eps * 1e12);
     if (counters[0] > 0)

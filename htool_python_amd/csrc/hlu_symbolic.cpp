@@ -202,9 +202,9 @@ struct Emitter {
         t.y_ld = Y.ld;
         // (the number of columns is the rank of a leaf: it must be the one the consumers of the block will see)
         int dep = Y.tr->dep_write(cell0[node], cell1[node]);
-        if (kref >= 0 && kref < (int)P.leaves.size()) dep = std::max(dep, dep_leaf_read(kref));
+        if (kref >= 0 && kref < (int)P.n_real_leaves) dep = std::max(dep, dep_leaf_read(kref));
         const int lev = emit(t, dep);
-        if (kref >= 0 && kref < (int)P.leaves.size()) note_leaf_read(kref, lev);
+        if (kref >= 0 && kref < (int)P.n_real_leaves) note_leaf_read(kref, lev);
         Y.tr->note_write(cell0[node], cell1[node], lev);
     }
     // Y[rows of the output side] (+)= -+ op(leaf restricted to (it, is)) X[rows of the input side]
@@ -281,9 +281,9 @@ struct Emitter {
     void close_window() {
         if (cur.empty()) return;
         P.factor.emplace_back();
+        P.factor.back().scratch_elems = scratch_used; // (the stage blocks of split runs are placed behind the window's own scratch)
         finish_program(cur, P.factor.back());
-        P.factor.back().scratch_elems = scratch_used;
-        P.scratch_elems = std::max(P.scratch_elems, scratch_used);
+        P.scratch_elems = std::max(P.scratch_elems, P.factor.back().scratch_elems);
         scratch_used = 0;
         window_base = max_level + 1;
         temp_tracks.clear();
@@ -321,6 +321,94 @@ struct Emitter {
             out.buckets.push_back(b);
         }
         out.n_levels = out.tasks.empty() ? 0 : hi - lo + 1;
+        if (planning_factor) split_long_runs(out);
+    }
+    // A run of many updates of ONE low-rank leaf inside one launch is a serial chain of truncations in one workgroup while the rest
+    // of the GPU waits for it.  Such a run is dealt out to several workgroups: part p accumulates its updates into a stage block of
+    // its own (an empty low-rank block of the leaf's shape in the scratch space, truncated at the end of the part), and a merge launch
+    // right behind adds the stage blocks to the leaf.  The order of the additions is fixed by the plan, so the result stays
+    // reproducible (it differs from the unsplit one by truncation errors of the size of the tolerance).
+    void split_long_runs(Program &G) {
+        const Params &prm = P.params;
+        std::vector<Task> tasks;
+        std::vector<Bucket> buckets;
+        std::vector<int64_t> seg;
+        tasks.reserve(G.tasks.size() + G.tasks.size() / 8);
+        int64_t stage_elems = 0;
+        for (const Bucket &b0 : G.buckets) {
+            Bucket b = b0;
+            b.begin = (int64_t)tasks.size();
+            if (b0.type != T_ADDLR) {
+                tasks.insert(tasks.end(), G.tasks.begin() + b0.begin, G.tasks.begin() + b0.end);
+                b.end = (int64_t)tasks.size();
+                if (b0.type == T_FINAL) {
+                    b.seg_begin = (int64_t)seg.size();
+                    for (int64_t q = b0.seg_begin; q < b0.seg_end; q++) seg.push_back(G.seg[(size_t)q] - b0.begin + b.begin);
+                    b.seg_end = (int64_t)seg.size();
+                    seg.push_back(b.end);
+                }
+                buckets.push_back(b);
+                continue;
+            }
+            std::vector<Task> merges;
+            b.seg_begin = (int64_t)seg.size();
+            for (int64_t q = b0.seg_begin; q < b0.seg_end; q++) {
+                const int64_t r0 = G.seg[(size_t)q], r1 = G.seg[(size_t)q + 1], cnt = r1 - r0;
+                const int target = G.tasks[(size_t)r0].leaf;
+                const Leaf L = P.leaves[(size_t)target];
+                const int parts = (int)std::min<int64_t>(prm.split_max_parts, cnt / std::max(prm.split_part, 1));
+                const int64_t need = ((((int64_t)L.m * 64 + 1) & ~(int64_t)1) + (((int64_t)L.n * 64 + 1) & ~(int64_t)1)) * parts;
+                if (L.kind != 1 || cnt <= prm.split_min || parts < 2 || G.scratch_elems + stage_elems + need > 2 * prm.window_scratch_elems) {
+                    seg.push_back((int64_t)tasks.size());
+                    tasks.insert(tasks.end(), G.tasks.begin() + r0, G.tasks.begin() + r1);
+                    continue;
+                }
+                for (int pt = 0; pt < parts; pt++) {
+                    const int64_t a = r0 + cnt * pt / parts, e = r0 + cnt * (pt + 1) / parts;
+                    Leaf S = L; // the stage block
+                    S.cap = 64; S.diag = -1; S.rank0 = 0;
+                    S.u = make_ref(SP_SCRATCH, G.scratch_elems + stage_elems);
+                    stage_elems += ((int64_t)L.m * 64 + 1) & ~(int64_t)1;
+                    S.v = make_ref(SP_SCRATCH, G.scratch_elems + stage_elems);
+                    stage_elems += ((int64_t)L.n * 64 + 1) & ~(int64_t)1;
+                    const int sid = (int)next_slot++;
+                    if ((size_t)sid >= P.leaves.size()) P.leaves.resize((size_t)sid + 1, Leaf{0, 0, 0, 0, 0, 0, 0, 0, -1, 0});
+                    P.leaves[(size_t)sid] = S;
+                    seg.push_back((int64_t)tasks.size());
+                    for (int64_t i = a; i < e; i++) { Task t = G.tasks[(size_t)i]; t.leaf = sid; tasks.push_back(t); }
+                    Task fin = blank(T_FINAL);
+                    fin.leaf = sid; fin.level = b0.level;
+                    tasks.push_back(fin);
+                    Task mg = blank(T_ADDLR);
+                    mg.leaf = target; mg.level = b0.level; mg.kref = sid;
+                    mg.m = L.m; mg.n = L.n;
+                    mg.x = S.u; mg.x_ld = L.m; mg.y = S.v; mg.y_ld = L.n;
+                    merges.push_back(mg);
+                    P.counts[T_FINAL]++; P.counts[T_ADDLR]++;
+                }
+            }
+            b.end = (int64_t)tasks.size();
+            b.seg_end = (int64_t)seg.size();
+            seg.push_back(b.end);
+            buckets.push_back(b);
+            if (!merges.empty()) { // (sorted by target already: the runs were)
+                Bucket mb = b0;
+                mb.begin = (int64_t)tasks.size();
+                mb.seg_begin = (int64_t)seg.size();
+                for (size_t i = 0; i < merges.size(); i++) {
+                    if (i == 0 || merges[i].leaf != merges[i - 1].leaf) seg.push_back((int64_t)tasks.size());
+                    tasks.push_back(merges[i]);
+                }
+                mb.end = (int64_t)tasks.size();
+                mb.seg_end = (int64_t)seg.size();
+                seg.push_back(mb.end);
+                buckets.push_back(mb);
+            }
+        }
+        G.tasks.swap(tasks);
+        G.buckets.swap(buckets);
+        G.seg.swap(seg);
+        G.scratch_elems += stage_elems;
     }
 
     // ---- the products C(t, s) -= A(t, r) B(r, s) ----
@@ -642,6 +730,7 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
     }
     P.factor_elems = fe;
     P.diag_elems = de;
+    P.n_real_leaves = (int64_t)in.size();
     E.next_slot = (int64_t)in.size();
     E.diag_bnode.assign(nn, -1);
     E.build_bnode(root, root, leaf_of);
@@ -665,7 +754,9 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
     for (size_t i = 0; i < in.size(); i++) E.ensure_final((int)i);
     E.close_window();
     P.n_slots = E.next_slot;
+    P.leaves.resize((size_t)E.next_slot, Leaf{0, 0, 0, 0, 0, 0, 0, 0, -1, 0}); // (one record per rank slot: the stage blocks have theirs, the others are unused)
     // the two solves: fresh dependency state, the factors are read only
+    E.planning_factor = false;
     for (int pass = 0; pass < 2; pass++) {
         for (Track &t : E.trU) t = Track();
         for (Track &t : E.trV) t = Track();

@@ -932,11 +932,11 @@ PYBIND11_MODULE(Htool, m) {
             }, "first"_a, "last"_a, "factor"_a, "diag"_a, "rank"_a, "norm0"_a, "norm2"_a, "counters"_a, "rhs"_a = py::none(), "ld_rhs"_a = 0, "nrhs"_a = 0, "scratch"_a = py::none())
         .def("tables", [](const PyHluPlan &s) {
                 const void *leaves, *diags;
-                int64_t info[3];
-                check(htool_hlu_plan_info(s.p, info, 3));
+                int64_t info[7];
+                check(htool_hlu_plan_info(s.p, info, 7));
                 check(htool_hlu_plan_tables(s.p, &leaves, &diags));
-                py::array_t<uint8_t> l({(py::ssize_t)info[1], (py::ssize_t)48});
-                std::memcpy(l.mutable_data(), leaves, (size_t)info[1] * 48);
+                py::array_t<uint8_t> l({(py::ssize_t)info[6], (py::ssize_t)48}); // (one record per rank slot)
+                std::memcpy(l.mutable_data(), leaves, (size_t)info[6] * 48);
                 py::array_t<uint8_t> d({(py::ssize_t)info[2], (py::ssize_t)24});
                 std::memcpy(d.mutable_data(), diags, (size_t)info[2] * 24);
                 return py::make_tuple(l, d);

@@ -63,10 +63,12 @@ class HostLU:
         self.diag = np.zeros(max(I["diag_elems"], 1))
         self.scratch = np.zeros(max(I["scratch_elems"], 1))
         self.rank = np.zeros(max(I["rank_slots"], 1), dtype=np.int32)
-        self.norm0 = np.full(max(I["leaves"], 1), -1.0)
-        self.norm2 = np.zeros(max(I["leaves"], 1))
+        self.norm0 = np.full(max(I["rank_slots"], 1), -1.0)  # (one per rank slot: the stage blocks of split update runs have theirs)
+        self.norm2 = np.zeros(max(I["rank_slots"], 1))
         self.counters = np.zeros(8, dtype=np.int64)
-        for i, L in enumerate(self.leaves):
+        self.n_leaves = I["leaves"]  # the operator's leaves; the records behind them are stage blocks in the scratch space
+        for i in range(self.n_leaves):
+            L = self.leaves[i]
             A, B = leaf_data(i)
             m, n = int(L["m"]), int(L["n"])
             if L["kind"] == 0:
@@ -115,4 +117,4 @@ class HostLU:
         return X[:, 0] if np.ndim(b_cluster) == 1 else X
 
     def ranks(self):
-        return self.rank[: self.info["leaves"]].copy()
+        return self.rank[: self.n_leaves].copy()

@@ -88,7 +88,7 @@ int pivoted_cholesky(double *G, double *R, int *piv, int K, int ld, double stop2
 void recompress(State &S, int l) {
     const Leaf &L = S.leaves[l];
     const int K = S.rank[l], m = L.m, n = L.n;
-    double *U = S.space[0] + L.u, *V = S.space[0] + L.v;
+    double *U = at(S, L.u), *V = at(S, L.v);
     S.counters[1]++;
     if (K == 0) { S.norm2[l] = 0; if (S.norm0[l] < 0) S.norm0[l] = 0; return; }
     const int ld = K;
@@ -225,7 +225,7 @@ void run_task(State &S, const Task &t) {
         auto xe = [&](int i, int c) { return (t.flags & F_XT) ? X[(int64_t)i * t.x_ld + c] : X[i + (int64_t)c * t.x_ld]; };
         auto ze = [&](int j, int c) { return (t.flags & F_YT) ? Z[(int64_t)j * t.y_ld + c] : Z[j + (int64_t)c * t.y_ld]; };
         if (L.kind == 0) {
-            double *D = S.space[0] + L.u;
+            double *D = at(S, L.u);
             for (int j = 0; j < t.n; j++)
                 for (int i = 0; i < t.m; i++) {
                     double s = 0;
@@ -234,7 +234,7 @@ void run_task(State &S, const Task &t) {
                 }
             break;
         }
-        double *U = S.space[0] + L.u, *V = S.space[0] + L.v;
+        double *U = at(S, L.u), *V = at(S, L.v);
         for (int c = 0; c < k; c++) {
             if (S.rank[t.leaf] == L.cap) recompress(S, t.leaf);
             const int f = S.rank[t.leaf];

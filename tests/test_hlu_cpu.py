@@ -66,3 +66,21 @@ def test_plan_refuses_leaves_that_do_not_tile():
     H, cl = make_case(400, 30, 1e-3)
     with pytest.raises(RuntimeError):
         Htool.HLUPlan(cl, H.leaves[:-3], 1e-3)
+
+
+def test_long_update_runs_are_split_over_stage_blocks():
+    """A run of many updates of one leaf in one launch is dealt out to several workgroups with a stage block each (hlu_symbolic.cpp:
+    split_long_runs); the result solves the system as well as the unsplit plan's."""
+    eps, eps_lu = 1e-3, 1e-4
+    H, cl = make_case(1500, 30, eps)
+    split = Htool.HLUPlan(cl, H.leaves, eps_lu)
+    info = dict(zip(ohlu.INFO, split.info()))
+    lu = ohlu.HostLU(split, H.leaf_data, eps_lu)
+    assert len(lu.leaves) > lu.n_leaves            # stage blocks exist
+    A = H.to_dense()
+    B = np.random.default_rng(5).normal(size=(1500, 2))
+    Xd = np.linalg.solve(A, B)
+    assert np.linalg.norm(lu.solve(B) - Xd) / np.linalg.norm(Xd) < 5 * eps_lu * max(1.0, np.sqrt(np.linalg.cond(A)) / 10)
+    other = ohlu.HostLU(split, H.leaf_data, eps_lu, shuffle=3)
+    assert np.array_equal(lu.factor, other.factor)  # the parts of a run and their merge are ordered by the plan, not by the schedule
+    assert info["leaves"] == len(H.leaves)

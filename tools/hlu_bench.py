@@ -33,11 +33,21 @@ else:
 torch.cuda.synchronize()
 size = H.shape[0]
 out = {"unknowns": size, "leaf": leaf, "eps": eps, "mode": mode, "build_s": round(time.time() - t0, 3), "hmatrix_GB": round(H.get_local_information().get("Device_bytes", 0) / 1e9, 3) if hasattr(H, "get_local_information") else None}
+shift_rel = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0   # the bench's C5 system: (shift I + H) x = b, shift = 8e-3 |H|
+shift = 0.0
+if shift_rel > 0:
+    v = np.random.RandomState(2).rand(size)
+    for _ in range(6):
+        w = H * v
+        norm_h = np.linalg.norm(w) / np.linalg.norm(v)
+        v = w / np.linalg.norm(w)
+    shift = shift_rel * norm_h
+out["shift"] = shift
 x_ref = np.random.RandomState(1).rand(size)
-bb = H * x_ref
+bb = H * x_ref + shift * x_ref
 for rep in range(2):
     t0 = time.time()
-    H.lu_factorization()
+    H.lu_factorization_shifted(shift) if shift > 0 else H.lu_factorization()
     torch.cuda.synchronize()
     out["lu_factorization_s_%d" % rep] = round(time.time() - t0, 3)
 info = H.factorization_info()

@@ -34,7 +34,7 @@ def snapshot(x):
 
 def differs(a, d):
     out = []
-    for i in range(len(a.leaves)):
+    for i in range(a.n_leaves):
         x, y = a.leaf_dense(i), d.leaf_dense(i)
         e = np.linalg.norm(x - y) / max(np.linalg.norm(x), 1e-300)
         if e > 1e-6:

@@ -18,14 +18,14 @@ eps, eps_lu = 1e-3, 1e-4
 H, cl = make_case(n, leaf, eps, eta, children)
 plan = Htool.HLUPlan(cl, H.leaves, eps_lu, window_tasks=wt, cap_factor=2 * np.log(eps_lu) / np.log(eps))
 host = ohlu.HostLU(plan, H.leaf_data, eps_lu, run=False)
-lr = host.leaves["kind"] == 1
+lr = host.leaves["kind"][:host.n_leaves] == 1
 names = ["FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF"]
 for w in range(host.info["windows"]):
     rank_before = host.rank.copy()
     dev = device_window(plan, host, w)
     host.run_window(w)
-    errs = np.zeros(len(host.leaves))
-    for i in range(len(host.leaves)):
+    errs = np.zeros(host.n_leaves)
+    for i in range(host.n_leaves):
         a, b = host.leaf_dense(i), dev.leaf_dense(i)
         errs[i] = np.linalg.norm(a - b) / max(np.linalg.norm(a), 1e-300)
     i = int(np.argmax(errs))
