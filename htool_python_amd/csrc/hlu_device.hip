@@ -89,19 +89,24 @@ __global__ __launch_bounds__(256) void hlu_apply_dense_kernel(Ctx c, const Task 
             double a[QC];
 #pragma unroll
             for (int col = 0; col < QC; col++) a[col] = 0.0;
-            if (!tr) {
-                for (int j = 0; j < t.n; j++) {
-                    const double mv = M[i + (long long)j * t.a_ld];
+            // (eight entries of the row of M are loaded before they are used: one load in flight per trip made the loop wait a memory
+            // round trip per entry -- 45 us for a 187 x 187 leaf, most of the time of a solve)
+            const long long ms = tr ? 1 : (long long)t.a_ld;
+            const double *Mi = tr ? M + (long long)i * t.a_ld : M + i;
+            int j = 0;
+            for (; j + 8 <= t.n; j += 8) {
+                double mv[8];
 #pragma unroll
-                    for (int col = 0; col < QC; col++) a[col] = fma(mv, sm[j * QC + col], a[col]);
-                }
-            } else {
-                const double *Mi = M + (long long)i * t.a_ld;
-                for (int j = 0; j < t.n; j++) {
-                    const double mv = Mi[j];
+                for (int u = 0; u < 8; u++) mv[u] = Mi[(long long)(j + u) * ms];
 #pragma unroll
-                    for (int col = 0; col < QC; col++) a[col] = fma(mv, sm[j * QC + col], a[col]);
-                }
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int col = 0; col < QC; col++) a[col] = fma(mv[u], sm[(j + u) * QC + col], a[col]);
+            }
+            for (; j < t.n; j++) {
+                const double mv = Mi[(long long)j * ms];
+#pragma unroll
+                for (int col = 0; col < QC; col++) a[col] = fma(mv, sm[j * QC + col], a[col]);
             }
 #pragma unroll
             for (int col = 0; col < QC; col++)
@@ -163,7 +168,17 @@ __global__ __launch_bounds__(256) void hlu_apply_lr_kernel(Ctx c, const Task *ta
             double s[QC];
 #pragma unroll
             for (int col = 0; col < QC; col++) s[col] = 0.0;
-            for (int l = 0; l < k; l++) {
+            int l = 0;
+            for (; l + 8 <= k; l += 8) { // (eight loads in flight, as above)
+                double av[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) av[u] = A[i + (long long)(l + u) * t.a_ld];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+#pragma unroll
+                    for (int col = 0; col < QC; col++) s[col] = fma(av[u], W[(l + u) * QC + col], s[col]);
+            }
+            for (; l < k; l++) {
                 const double av = A[i + (long long)l * t.a_ld];
 #pragma unroll
                 for (int col = 0; col < QC; col++) s[col] = fma(av, W[l * QC + col], s[col]);
@@ -918,6 +933,13 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
     // (the caller's stream as it is: NULL is the legacy default stream, which orders this against the caller's other default-stream work and
     // against every blocking stream -- substituting the operator's own stream here would let a product on ANOTHER handle's stream overtake it)
     run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, (hipStream_t)stream);
+    if (getenv("HTOOL_HLU_PROFILE") && atoi(getenv("HTOOL_HLU_PROFILE")) > 1) { // (every launch was waited for: where the time of a solve goes)
+        static const char *names[T_NTYPES] = {"FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF"};
+        for (int q = 1; q <= 2; q++) {
+            fprintf(stderr, "[hlu solve profile] %-12s %9.4f s  %8lld launches  %10lld tasks  longest launch %.6f s\n", names[q], g_prof_seconds[q], g_prof_launches[q], g_prof_items[q], g_prof_longest[q]);
+            g_prof_seconds[q] = 0; g_prof_launches[q] = 0; g_prof_items[q] = 0; g_prof_longest[q] = 0;
+        }
+    }
 }
 
 // ---- the factorisation of an operator -----------------------------------------------------------------------------------------

@@ -14,6 +14,17 @@ import Htool  # noqa: E402
 import torch  # noqa: E402
 from htool_python_amd.workloads import points_in_sphere  # noqa: E402
 
+import threading
+
+
+def _heartbeat():  # (a long factorisation prints nothing by itself; the GPU pool takes seven silent minutes for a hang)
+    t0 = time.time()
+    while True:
+        time.sleep(45)
+        print("[hlu_bench] %.0f s" % (time.time() - t0), file=sys.stderr, flush=True)
+
+
+threading.Thread(target=_heartbeat, daemon=True).start()
 n = int(sys.argv[1])
 leaf = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3
@@ -45,7 +56,7 @@ if shift_rel > 0:
 out["shift"] = shift
 x_ref = np.random.RandomState(1).rand(size)
 bb = H * x_ref + shift * x_ref
-for rep in range(2):
+for rep in range(int(os.environ.get("HLU_BENCH_REPS", "2"))):
     t0 = time.time()
     H.lu_factorization_shifted(shift) if shift > 0 else H.lu_factorization()
     torch.cuda.synchronize()
