@@ -83,7 +83,7 @@ struct Params {
     double cap_factor = 2.5;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
     int64_t window_scratch_elems = (int64_t)1 << 29; // a window of the task stream may hold this much scratch (4 GB of doubles)
     int64_t window_tasks = (int64_t)1 << 23;
-    int split_min = 12, split_part = 8, split_max_parts = 16; // a run of more than split_min updates of one low-rank leaf in one launch is dealt out to
+    int split_min = 8, split_part = 4, split_max_parts = 24; // a run of more than split_min updates of one low-rank leaf in one launch is dealt out to
                                                               // up to split_max_parts workgroups (>= split_part updates each), each with a stage block of its own
 };
 

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 
 #include "capi_internal.hpp"
 #include "device_internal.hpp"
@@ -689,6 +690,15 @@ __global__ __launch_bounds__(256) void hlu_mirror_kernel(Ctx c, const int2 *pair
     if (threadIdx.x == 0) c.rank[pairs[blockIdx.x].y] = k;
     (void)rank_known;
 }
+// After the factorisation every leaf moves to a tight arena (its rank in columns instead of the 64 of room): one workgroup per leaf
+__global__ __launch_bounds__(256) void hlu_compact_kernel(const double *from, double *to, const Leaf *old_leaves, const Leaf *new_leaves, const int *rank, int n_leaves) {
+    const int l = blockIdx.x;
+    if (l >= n_leaves) return;
+    const Leaf A = old_leaves[l], B = new_leaves[l];
+    const long long nu = A.kind == 0 ? (long long)A.m * A.n : (long long)A.m * rank[l], nv = A.kind == 0 ? 0 : (long long)A.n * rank[l];
+    for (long long e = threadIdx.x; e < nu; e += 256) to[B.u + e] = from[A.u + e];
+    for (long long e = threadIdx.x; e < nv; e += 256) to[B.v + e] = from[A.v + e];
+}
 template <typename T>
 __global__ void hlu_permute_rows_kernel(const T *src, T *dst, const int *perm, int n, int mu, int gather) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1025,6 +1035,54 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
             g_prof_seconds[q] = 0; g_prof_launches[q] = 0; g_prof_items[q] = 0; g_prof_longest[q] = 0;
         }
     }
+    int64_t arena_peak_bytes = (P.factor_elems + P.diag_elems) * 8;
+    static const bool no_compact = getenv("HTOOL_HLU_COMPACT") && std::string(getenv("HTOOL_HLU_COMPACT")) == "0";
+    if (!no_compact) { // the factors keep only their rank in columns: a tight arena replaces the one with 64 columns of room per leaf
+        Plan &PW = *f->plan;
+        const size_t nl = (size_t)PW.n_real_leaves;
+        std::vector<int> r(nl);
+        HIP_OK(hipMemcpy(r.data(), f->rank, nl * 4, hipMemcpyDeviceToHost));
+        std::vector<Leaf> tight(PW.leaves.begin(), PW.leaves.begin() + nl);
+        int64_t fe = 0;
+        for (size_t i = 0; i < nl; i++) {
+            Leaf &L = tight[i];
+            L.u = fe;
+            if (L.kind == 1) {
+                L.cap = std::max(r[i], 1);
+                fe += ((int64_t)L.m * L.cap + 1) & ~(int64_t)1;
+                L.v = fe;
+                fe += ((int64_t)L.n * L.cap + 1) & ~(int64_t)1;
+            } else fe += ((int64_t)L.m * L.n + 1) & ~(int64_t)1;
+        }
+        double *packed = nullptr;
+        if (hipMalloc((void **)&packed, std::max<size_t>((size_t)fe * 8, 16)) == hipSuccess) {
+            DevBuf d_new;
+            d_new.alloc(nl * sizeof(Leaf));
+            HIP_OK(hipMemcpy(d_new.p, tight.data(), nl * sizeof(Leaf), hipMemcpyHostToDevice));
+            if (nl) hipLaunchKernelGGL(hlu_compact_kernel, dim3((unsigned)nl), dim3(256), 0, D->stream, f->factor, packed, f->leaves, d_new.as<Leaf>(), f->rank, (int)nl);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(D->stream));
+            // the solve programs refer to rows of the factors: moved leaf by leaf
+            for (Program *G : {&PW.solve_n, &PW.solve_t})
+                for (Task &t : G->tasks) {
+                    if (t.leaf < 0 || (size_t)t.leaf >= nl) continue;
+                    const Leaf &O = PW.leaves[(size_t)t.leaf], &N = tight[(size_t)t.leaf];
+                    auto move = [&](int64_t ref) -> int64_t {
+                        if ((int)(ref >> SPACE_SHIFT) != SP_FACTOR) return ref;
+                        const int64_t off = ref & (((int64_t)1 << SPACE_SHIFT) - 1);
+                        if (O.kind == 1 && off >= O.v && off < O.v + (int64_t)O.n * O.cap) return make_ref(SP_FACTOR, off - O.v + N.v);
+                        return make_ref(SP_FACTOR, off - O.u + N.u);
+                    };
+                    if (t.type == T_APPLY_LR) { t.a = move(t.a); t.b = move(t.b); }
+                    else if (t.type == T_APPLY_DENSE && !(t.flags & F_INPLACE)) t.a = move(t.a);
+                }
+            for (size_t i = 0; i < nl; i++) PW.leaves[i] = tight[i];
+            HIP_OK(hipMemcpy(f->leaves, PW.leaves.data(), nl * sizeof(Leaf), hipMemcpyHostToDevice));
+            (void)hipFree(f->factor);
+            f->factor = packed;
+            PW.factor_elems = fe;
+        } else (void)hipGetLastError(); // (no room for the second arena: the factors stay where they are)
+    }
     hlu_upload_solves(*f);
     long long counters[8];
     HIP_OK(hipMemcpy(counters, f->counters, sizeof(counters), hipMemcpyDeviceToHost));
@@ -1039,13 +1097,13 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
     f->seconds[3] = wall_seconds() - t_begin;
     int64_t *s = f->stats;
     s[0] = P.n; s[1] = P.n_real_leaves; s[2] = tasks; s[3] = launches; s[4] = (int64_t)P.factor.size();
-    s[5] = (P.factor_elems + P.diag_elems) * 8; s[6] = P.scratch_elems * 8; s[7] = counters[0]; s[8] = counters[1]; s[9] = counters[2]; s[10] = counters[3];
+    s[5] = (P.factor_elems + P.diag_elems) * 8; s[6] = arena_peak_bytes + P.scratch_elems * 8; // (the factors as they stay resident; arena with 64 columns of room per leaf + scratch while factorising) s[7] = counters[0]; s[8] = counters[1]; s[9] = counters[2]; s[10] = counters[3];
     s[11] = (int64_t)P.solve_n.tasks.size(); s[12] = (int64_t)P.solve_n.buckets.size(); s[13] = rank_sum; s[14] = lr_rows; s[15] = (int64_t)(prm.eps * 1e12);
     if (counters[0] > 0)
         log_message(LOG_WARNING, strprintf("hierarchical LU: %lld truncations were cut at the capacity of their leaf (accuracy below the asked %.1e: raise HTOOL_HLU_CAP_FACTOR, now %.2f)",
                                            counters[0], prm.eps, prm.cap_factor));
     log_message(LOG_INFO, strprintf("hierarchical %s of the %d x %d operator: plan %.3f s (%lld tasks, %lld launches, %d windows), leaves into the factor arena %.3f s, factorisation %.3f s; "
-                                    "factors %.2f GB, scratch %.2f GB, eps %.1e, mean rank %.1f", kind == 1 ? "LU" : "Cholesky (as LU)", P.n, P.n, f->seconds[0], (long long)tasks, (long long)launches,
+                                    "factors %.2f GB resident (%.2f GB of arena and scratch while factorising), eps %.1e, mean rank %.1f", kind == 1 ? "LU" : "Cholesky (as LU)", P.n, P.n, f->seconds[0], (long long)tasks, (long long)launches,
                                     (int)P.factor.size(), f->seconds[1], f->seconds[2], s[5] / 1e9, s[6] / 1e9, prm.eps, lr_rows ? (double)rank_sum / lr_rows : 0.0));
     // the programs of the factorisation are not needed any more (the solves are on the device)
     for (Program &w : f->plan->factor) { std::vector<Task>().swap(w.tasks); std::vector<int64_t>().swap(w.seg); }

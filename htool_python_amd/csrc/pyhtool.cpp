@@ -552,7 +552,7 @@ static void declare_coefficient_classes(py::module &m, const std::string &prefix
                 static const char *kinds[] = {"none", "dense host", "dense device", "hierarchical"};
                 d["kind"] = kinds[v[0] < 0 || v[0] > 3 ? 0 : v[0]];
                 if (v[0] == 3) {
-                    static const char *names[] = {"unknowns", "leaves", "tasks", "launches", "windows", "factor_bytes", "scratch_bytes", "truncations_at_capacity", "truncations", "appended_columns",
+                    static const char *names[] = {"unknowns", "leaves", "tasks", "launches", "windows", "factor_bytes", "peak_bytes", "truncations_at_capacity", "truncations", "appended_columns",
                                                   "dense_product_columns", "solve_tasks", "solve_launches", "rank_weight", "rows_plus_columns", "eps_e12"};
                     for (int i = 0; i < 16; i++) d[names[i]] = v[1 + i];
                     d["plan_s"] = sec[0]; d["unpack_s"] = sec[1]; d["factor_s"] = sec[2]; d["total_s"] = sec[3];

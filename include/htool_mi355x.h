@@ -379,7 +379,7 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
  * each, struct hm::hlu::Task), launch buckets and target runs of one window of the factorisation (which >= 0) or of the
  * solves (-1: 'N', -2: 'T'); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
 /* what htool_hmatrix_lu_factorization / _cholesky_factorization left behind: out17[0] = 0 nothing, 1 dense on the host, 2 dense on
- * the device, 3 hierarchical; for 3, out17[1..16] = unknowns, leaves, tasks, launches, windows, bytes of the factors, bytes of scratch,
+ * the device, 3 hierarchical; for 3, out17[1..16] = unknowns, leaves, tasks, launches, windows, bytes of the factors as they stay resident (tight: their rank in columns), bytes of the arena (64 columns of room per leaf) and scratch while factorising,
  * truncations cut at a leaf's capacity, truncations, appended columns, columns out of dense-leaf products, tasks and launches of one
  * solve, sum of rank x (rows + columns) over the low-rank leaves, sum of (rows + columns), tolerance x 1e12; seconds4 = plan, leaves
  * into the factor arena, factorisation, total. */

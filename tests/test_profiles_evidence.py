@@ -61,3 +61,16 @@ def test_bench_line_agrees_with_the_rocprof_summary():
     assert abs(avg_us - prof["roofline"]["launch_us"]) < 0.01 * avg_us
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "full_operator" in cpu
+
+
+def test_hierarchical_lu_evidence_is_consistent():
+    """profiles/r04_hlu_*.json (tools/hlu_bench.py): hierarchical factorisations, far below a dense copy in memory, solving their system."""
+    for name, unknowns in (("r04_hlu_12k.json", 12000), ("r04_hlu_c5_block_62500.json", 62500), ("r04_hlu_250k_symmetric_shifted.json", 250000)):
+        d = _line(name)
+        info = d["info"]
+        assert d["unknowns"] == unknowns and info["kind"] == "hierarchical" and info["unknowns"] == unknowns
+        assert info["factor_bytes"] < (0.8 if unknowns < 20000 else 0.3) * 8 * unknowns * unknowns
+        assert info["truncations_at_capacity"] <= 0.01 * info["truncations"]
+        assert d["solve_error"] < 1e-8 and d["solve_error"] <= d["solve_error_unrefined"]
+        assert abs(d["mean_rank_factors"] - info["rank_weight"] / info["rows_plus_columns"]) < 0.01
+        assert info["factor_s"] <= max(v for k, v in d.items() if k.startswith("lu_factorization_s_")) + 1e-3  # (the statistics are the last repetition's)
