@@ -68,9 +68,7 @@ __global__ __launch_bounds__(256) void hlu_fill_kernel(Ctx c, const Task *tasks)
     }
 }
 
-__global__ __launch_bounds__(256) void hlu_apply_dense_kernel(Ctx c, const Task *tasks) {
-    extern __shared__ double sm[]; // n x QC
-    const Task t = tasks[blockIdx.x];
+__device__ __forceinline__ void apply_dense_body(const Ctx &c, const Task &t, double *sm /* n x QC */) {
     const int tid = threadIdx.x, q = cols_of(c, t);
     const double *M = at(c, t.a), *x = at(c, t.x);
     double *y = at(c, t.y);
@@ -119,10 +117,13 @@ __global__ __launch_bounds__(256) void hlu_apply_dense_kernel(Ctx c, const Task 
     }
 }
 
-__global__ __launch_bounds__(256) void hlu_apply_lr_kernel(Ctx c, const Task *tasks) {
-    __shared__ double W[64 * QC];
-    __shared__ double red[4][64];
+__global__ __launch_bounds__(256) void hlu_apply_dense_kernel(Ctx c, const Task *tasks) {
+    extern __shared__ double sm[];
     const Task t = tasks[blockIdx.x];
+    apply_dense_body(c, t, sm);
+}
+
+__device__ __forceinline__ void apply_lr_body(const Ctx &c, const Task &t, double *W /* 64 x QC */, double (*red)[64] /* 4 x 64 */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = cols_of(c, t), k = c.rank[t.leaf];
     const double *A = at(c, t.a), *B = at(c, t.b), *x = at(c, t.x);
@@ -193,6 +194,22 @@ __global__ __launch_bounds__(256) void hlu_apply_lr_kernel(Ctx c, const Task *ta
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void hlu_apply_lr_kernel(Ctx c, const Task *tasks) {
+    __shared__ double W[64 * QC];
+    __shared__ double red[4][64];
+    const Task t = tasks[blockIdx.x];
+    apply_lr_body(c, t, W, red);
+}
+// the dense and the low-rank applications of ONE level in one launch (a solve is thousands of small levels: every launch counts)
+__global__ __launch_bounds__(256) void hlu_apply_kernel(Ctx c, const Task *tasks) {
+    extern __shared__ double sm[];
+    __shared__ double W[64 * QC];
+    __shared__ double red[4][64];
+    const Task t = tasks[blockIdx.x];
+    if (t.type == T_APPLY_DENSE) apply_dense_body(c, t, sm);
+    else apply_lr_body(c, t, W, red);
 }
 
 __device__ __forceinline__ int keep_max(const Leaf &L) { return L.cap - max(4, L.cap / 8); }
@@ -737,6 +754,7 @@ void attributes_once() {
     if (done) return;
     HIP_OK(hipFuncSetAttribute((const void *)hlu_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)update_lds_bytes(64)));
     HIP_OK(hipFuncSetAttribute((const void *)hlu_apply_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HLU_MAX_DIM * QC * (int)sizeof(double)));
+    HIP_OK(hipFuncSetAttribute((const void *)hlu_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HLU_MAX_DIM * QC * (int)sizeof(double)));
     HIP_OK(hipFuncSetAttribute((const void *)hlu_getrf_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 1024 * (int)sizeof(double)));
     done = true;
 }
@@ -754,9 +772,20 @@ void run_program(const Program &G, const DevProgram &dp, const Ctx &c, const std
     long long launched = 0;
     static const bool profile = getenv("HTOOL_HLU_PROFILE") && atoi(getenv("HTOOL_HLU_PROFILE")) > 0;
     if (profile) HIP_OK(hipStreamSynchronize(st));
-    for (const Bucket &b : G.buckets) {
+    for (size_t bi = 0; bi < G.buckets.size(); bi++) {
+        const Bucket &b = G.buckets[bi];
         if (limit >= 0 && launched++ >= limit) break;
         const double tp0 = profile ? wall_seconds() : 0.0;
+        if (b.type == T_APPLY_DENSE && bi + 1 < G.buckets.size() && G.buckets[bi + 1].type == T_APPLY_LR && G.buckets[bi + 1].level == b.level && G.buckets[bi + 1].begin == b.end &&
+            limit < 0 && !profile) { // both kinds of application of this level in one launch
+            const Bucket &b2 = G.buckets[bi + 1];
+            int nmax = 1;
+            for (int64_t i = b.begin; i < b.end; i++) nmax = std::max(nmax, G.tasks[(size_t)i].n);
+            HM_CHECK(nmax <= HLU_MAX_DIM, "hierarchical LU: a dense leaf has more rows or columns than the kernels stage on chip");
+            hipLaunchKernelGGL(hlu_apply_kernel, dim3((unsigned)(b2.end - b.begin)), dim3(256), (size_t)nmax * QC * sizeof(double), st, c, dp.tasks + b.begin);
+            bi++;
+            continue;
+        }
         const unsigned n = (unsigned)(b.end - b.begin);
         const Task *t0 = dp.tasks + b.begin;
         switch (b.type) {
@@ -1097,7 +1126,8 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
     f->seconds[3] = wall_seconds() - t_begin;
     int64_t *s = f->stats;
     s[0] = P.n; s[1] = P.n_real_leaves; s[2] = tasks; s[3] = launches; s[4] = (int64_t)P.factor.size();
-    s[5] = (P.factor_elems + P.diag_elems) * 8; s[6] = arena_peak_bytes + P.scratch_elems * 8; // (the factors as they stay resident; arena with 64 columns of room per leaf + scratch while factorising) s[7] = counters[0]; s[8] = counters[1]; s[9] = counters[2]; s[10] = counters[3];
+    s[5] = (P.factor_elems + P.diag_elems) * 8; s[6] = arena_peak_bytes + P.scratch_elems * 8; // (the factors as they stay resident; arena with 64 columns of room per leaf + scratch while factorising)
+    s[7] = counters[0]; s[8] = counters[1]; s[9] = counters[2]; s[10] = counters[3];
     s[11] = (int64_t)P.solve_n.tasks.size(); s[12] = (int64_t)P.solve_n.buckets.size(); s[13] = rank_sum; s[14] = lr_rows; s[15] = (int64_t)(prm.eps * 1e12);
     if (counters[0] > 0)
         log_message(LOG_WARNING, strprintf("hierarchical LU: %lld truncations were cut at the capacity of their leaf (accuracy below the asked %.1e: raise HTOOL_HLU_CAP_FACTOR, now %.2f)",
