@@ -4,6 +4,8 @@
 // src/htool/hmatrix/hmatrix.hpp:58-94 (lib/htool itself is not vendored: the algorithm is the textbook
 // block-recursive H-LU of Hackbusch / Bebendorf on the strong-admissibility block tree).
 //
+// (symmetric positive definite operators: the same with A = L L^T on the lower triangle only -- Params::symmetric, half the work:
+//   CHOL(t): CHOL(t_i); A(t_j,t_i) <- A(t_j,t_i) L(t_i,t_i)^-T (j > i); A(t_j,t_k) <- A(t_j,t_k) - A(t_j,t_i) A(t_k,t_i)^T (j >= k > i) )
 //   LU(t):  for the children t_i of t in order:  LU(t_i);
 //                                                A(t_i,t_j) <- L(t_i,t_i)^-1 A(t_i,t_j),  A(t_j,t_i) <- A(t_j,t_i) U(t_i,t_i)^-1   (j > i)
 //                                                A(t_j,t_k) <- A(t_j,t_k) - A(t_j,t_i) A(t_i,t_k)                                (j, k > i)
@@ -34,6 +36,7 @@ enum TaskFlags : int32_t {
     F_SUB = 8,       // alpha = -1
     F_XT = 16,       // x is a transposed view: element (i, c) at x + i * x_ld + c  (otherwise x + i + c * x_ld)
     F_YT = 32,       // the same for y
+    F_SYM = 64,      // GETRF: the leaf is symmetric positive definite -- no pivoting, and the inverse factors are those of its CHOLESKY factor (L_c^-1 and its transpose)
 };
 // where an element offset points (top bits of a 64-bit reference)
 enum Space : int { SP_FACTOR = 0, SP_DIAG = 1, SP_SCRATCH = 2, SP_RHS = 3 };
@@ -46,7 +49,7 @@ struct Task { // 96 bytes
     int32_t kref;   // number of columns: >= 0 rank slot, -1 kconst, -2 the run-time number of right-hand sides
     int32_t kconst;
     int32_t m, n;   // APPLY: rows of Y, rows of X;  ADDLR: rows / columns of the updated sub-block;  DDPROD: rows / columns of the product
-    int32_t r0, c0; // ADDLR: origin of the sub-block inside the target leaf;  DDPROD: r0 = inner dimension
+    int32_t r0, c0; // ADDLR: origin of the sub-block inside the target leaf;  DDPROD: r0 = inner dimension (F_TRANS: b is n x q, the product is a b^T)
     int32_t a_ld, b_ld, x_ld, y_ld; // (x_ld / y_ld of SP_RHS references: the run-time leading dimension)
     int64_t a, b;   // APPLY_DENSE: a = M;  APPLY_LR: a = rows of the output-side factor, b = rows of the input-side factor;  DDPROD: a (m x q), b (q x n)
     int64_t x, y;   // APPLY: input / output thin blocks;  ADDLR: X (m x k) and Z (n x k), update = -+ X Z^T;  DDPROD: outputs X' (ld m), Z' (ld n)
@@ -83,6 +86,7 @@ struct Params {
     double cap_factor = 2.5;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
     int64_t window_scratch_elems = (int64_t)1 << 29; // a window of the task stream may hold this much scratch (4 GB of doubles)
     int64_t window_tasks = (int64_t)1 << 23;
+    bool symmetric = false; // the operator is symmetric positive definite and only its LOWER triangle (diagonal leaves included) is given: H-Cholesky, A = L L^T
     int split_min = 8, split_part = 4, split_max_parts = 24; // a run of more than split_min updates of one low-rank leaf in one launch is dealt out to
                                                               // up to split_max_parts workgroups (>= split_part updates each), each with a stage block of its own
 };

@@ -514,7 +514,8 @@ __global__ __launch_bounds__(256) void hlu_ddprod_kernel(Ctx c, const Task *task
     __shared__ double tiles[2 * 64 * 17];
     for (int e = tid; e < m * n; e += 256) W[e] = 0.0;
     __syncthreads();
-    wg_gemm_nt(W, m, m, n, qn, 1.0, A, 1, t.a_ld, B, t.b_ld, 1, tiles);
+    if (t.flags & F_TRANS) wg_gemm_nt(W, m, m, n, qn, 1.0, A, 1, t.a_ld, B, 1, t.b_ld, tiles); // (b is n x q: a b^T)
+    else wg_gemm_nt(W, m, m, n, qn, 1.0, A, 1, t.a_ld, B, t.b_ld, 1, tiles);
     const double tol2 = 0.01 * c.eps * c.eps * fmax(c.norm0[t.leaf], 0.0);
     int k = 0;
     while (k < t.kconst) {
@@ -555,17 +556,19 @@ __global__ __launch_bounds__(256) void hlu_getrf_kernel(Ctx c, const Task *tasks
     const Diag Dg = c.diags[L.diag];
     const int tid = threadIdx.x, m = L.m;
     double *A = c.space[0] + L.u, *Li = c.space[1] + Dg.linv, *Ui = c.space[1] + Dg.uinv;
+    const bool sym = t.flags & F_SYM; // symmetric positive definite leaf: no pivoting (L U with U = D L^T), a positive diagonal expected
     for (int j = 0; j < m; j++) {
         double best = -1.0;
         int bi = j;
-        for (int i = j + tid; i < m; i += 256) { const double v = fabs(A[i + (long long)j * m]); if (v > best) { best = v; bi = i; } }
+        if (!sym) for (int i = j + tid; i < m; i += 256) { const double v = fabs(A[i + (long long)j * m]); if (v > best) { best = v; bi = i; } }
+        else if (tid == 0) best = A[j + (long long)j * m] > 0 ? 1.0 : 0.0;
         rbest[tid] = best; ridx[tid] = bi;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
             if (tid < s && (rbest[tid + s] > rbest[tid] || (rbest[tid + s] == rbest[tid] && ridx[tid + s] < ridx[tid]))) { rbest[tid] = rbest[tid + s]; ridx[tid] = ridx[tid + s]; }
             __syncthreads();
         }
-        const int p = ridx[0];
+        const int p = sym ? j : ridx[0];
         if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) atomicAdd((unsigned long long *)&c.counters[4], 1ull); }
         __syncthreads();
         if (p != j) for (int col = tid; col < m; col += 256) { const double a = A[j + (long long)col * m]; A[j + (long long)col * m] = A[p + (long long)col * m]; A[p + (long long)col * m] = a; }
@@ -608,6 +611,11 @@ __global__ __launch_bounds__(256) void hlu_getrf_kernel(Ctx c, const Task *tasks
         }
         __syncthreads();
     }
+    if (sym) { // the inverse of the Cholesky factor L D^(1/2): rows of L^-1 scaled by 1 / sqrt(d), and its transpose
+        for (int e = tid; e < m * m; e += 256) { const int i = e % m; Li[e] /= sqrt(A[i + (long long)i * m]); }
+        __syncthreads();
+        for (int e = tid; e < m * m; e += 256) { const int i = e % m, col = e / m; Ui[e] = Li[col + (long long)i * m]; }
+    }
 }
 
 // The same for diagonal leaves of at most 128 rows, with the matrix in LDS: the elimination and the substitutions (blocks of nb
@@ -626,17 +634,19 @@ __global__ __launch_bounds__(256) void hlu_getrf_lds_kernel(Ctx c, const Task *t
     const int nb = max(1, min(m, (lds_doubles - m * m) / max(m, 1)));
     for (int e = tid; e < m * m; e += 256) As[e] = A[e];
     __syncthreads();
+    const bool sym = t.flags & F_SYM;
     for (int j = 0; j < m; j++) {
         double best = -1.0;
         int bi = j;
-        for (int i = j + tid; i < m; i += 256) { const double v = fabs(As[i + j * m]); if (v > best) { best = v; bi = i; } }
+        if (!sym) for (int i = j + tid; i < m; i += 256) { const double v = fabs(As[i + j * m]); if (v > best) { best = v; bi = i; } }
+        else if (tid == 0) best = As[j + j * m] > 0 ? 1.0 : 0.0;
         rbest[tid] = best; ridx[tid] = bi;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
             if (tid < s && (rbest[tid + s] > rbest[tid] || (rbest[tid + s] == rbest[tid] && ridx[tid + s] < ridx[tid]))) { rbest[tid] = rbest[tid + s]; ridx[tid] = ridx[tid + s]; }
             __syncthreads();
         }
-        const int p = ridx[0];
+        const int p = sym ? j : ridx[0];
         if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) atomicAdd((unsigned long long *)&c.counters[4], 1ull); }
         __syncthreads();
         if (p != j) for (int col = tid; col < m; col += 256) { const double a = As[j + col * m]; As[j + col * m] = As[p + col * m]; As[p + col * m] = a; }
@@ -669,8 +679,11 @@ __global__ __launch_bounds__(256) void hlu_getrf_lds_kernel(Ctx c, const Task *t
             for (int e = tid; e < nn * w; e += 256) { const int i = j + 1 + e % nn, cc = e / nn; Bs[i + cc * m] -= As[i + j * m] * Bs[j + cc * m]; }
             __syncthreads();
         }
+        if (sym) for (int e = tid; e < m * w; e += 256) Bs[e] /= sqrt(As[(e % m) * (m + 1)]); // rows of L^-1 scaled: the inverse of the Cholesky factor L D^(1/2)
+        __syncthreads();
         for (int e = tid; e < m * w; e += 256) Li[(long long)c0 * m + e] = Bs[e];
         __syncthreads();
+        if (sym) continue; // (its second inverse factor is the transpose of the first: below)
         // U^-1, columns c0 .. c0 + w
         for (int e = tid; e < m * w; e += 256) { const int i = e % m, cc = e / m; Bs[e] = i == c0 + cc ? 1.0 : 0.0; }
         __syncthreads();
@@ -683,6 +696,11 @@ __global__ __launch_bounds__(256) void hlu_getrf_lds_kernel(Ctx c, const Task *t
         }
         for (int e = tid; e < m * w; e += 256) Ui[(long long)c0 * m + e] = Bs[e];
         __syncthreads();
+    }
+    if (sym) {
+        __threadfence_block();
+        __syncthreads();
+        for (int e = tid; e < m * m; e += 256) { const int i = e % m, col = e / m; Ui[e] = Li[col + (long long)i * m]; }
     }
 }
 
@@ -988,7 +1006,24 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
 // refines its answer against the operator's product (device_hlu_solve_host), which is what meets the bar of the reference's tests
 // (tests/test_hmatrix.py:104: error below epsilon).
 // Throws hm::Error when the operator is not one this factorisation covers (the caller falls back to the dense one).
+static DeviceHLU *hlu_factor_impl(const HMatrix &H, int kind, double shift, double eps_lu, bool symmetric);
+// A symmetric operator (declared 'S', or any operator handed to cholesky_factorization, whose contract is that only the UPLO triangle is
+// looked at) is factorised as A = L L^T on its lower triangle -- half the work; an LU request that meets a matrix which is not positive
+// definite starts again as an LU (HTOOL_HLU_SYMMETRIC=0: always the LU).
 DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double eps_lu) {
+    static const bool sym_off = getenv("HTOOL_HLU_SYMMETRIC") && std::string(getenv("HTOOL_HLU_SYMMETRIC")) == "0";
+    const bool upper_only = H.one_triangle && H.params.uplo == 'U'; // (stored as the upper triangle: served by the LU on mirrored leaves)
+    const bool symmetric = !sym_off && !H.is_complex && !upper_only && (kind == 2 || H.params.symmetry == 'S');
+    if (!symmetric) return hlu_factor_impl(H, kind, shift, eps_lu, false);
+    try {
+        return hlu_factor_impl(H, kind, shift, eps_lu, true);
+    } catch (const Error &e) {
+        if (kind == 2 || std::string(e.what()).find("not positive definite") == std::string::npos) throw;
+        log_message(LOG_DEBUG, "lu_factorization of a symmetric operator: not positive definite, factorising as an LU");
+        return hlu_factor_impl(H, kind, shift, eps_lu, false);
+    }
+}
+static DeviceHLU *hlu_factor_impl(const HMatrix &H, int kind, double shift, double eps_lu, bool symmetric) {
     DeviceHMatrix *D = H.dev;
     HM_CHECK(D != nullptr, "H-matrix has no device data");
     HM_CHECK(!H.is_complex, "hierarchical LU: complex operators are factorised by the dense fallback");
@@ -998,16 +1033,23 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
     const ClusterTree &T = *H.tc;
     const std::vector<BlockRec> &blocks = H.blocks();
     std::vector<LeafIn> in;
+    std::vector<int64_t> sel; // plan leaf i = block sel[i] of the operator (then the mirrored ones)
     in.reserve(blocks.size() * (H.one_triangle ? 2 : 1));
-    for (const BlockRec &b : blocks) in.push_back({b.t_node, b.s_node, b.rank < 0 ? -1 : b.rank});
+    for (size_t i = 0; i < blocks.size(); i++) {
+        const BlockRec &b = blocks[i];
+        if (symmetric && b.t_off < b.s_off) continue; // (the lower triangle and the diagonal leaves only)
+        in.push_back({b.t_node, b.s_node, b.rank < 0 ? -1 : b.rank});
+        sel.push_back((int64_t)i);
+    }
     std::vector<int2> mirrors; // (stored leaf, its transposed twin)
-    if (H.one_triangle)
+    if (H.one_triangle && !symmetric)
         for (size_t i = 0; i < blocks.size(); i++)
             if (blocks[i].t_node != blocks[i].s_node) {
                 mirrors.push_back(make_int2((int)i, (int)in.size()));
                 in.push_back({blocks[i].s_node, blocks[i].t_node, blocks[i].rank < 0 ? -1 : blocks[i].rank});
             }
     Params prm;
+    prm.symmetric = symmetric;
     prm.eps = eps_lu > 0 ? eps_lu : 0.1 * H.params.epsilon;
     if (const char *e = getenv("HTOOL_HLU_EPS")) if (atof(e) > 0) prm.eps = atof(e);
     HM_CHECK(prm.eps >= 1e-7, "hierarchical LU: tolerances below 1e-7 are beyond the Gram-matrix truncation of the low-rank arithmetic (the dense factorisation takes over)");
@@ -1034,9 +1076,9 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
     hlu_allocate(*f);
     const double t_unpack = wall_seconds();
     {
-        std::vector<int64_t> ids(blocks.size()), uo(blocks.size()), vo(blocks.size());
-        for (size_t i = 0; i < blocks.size(); i++) { ids[i] = (int64_t)i; uo[i] = P.leaves[i].u; vo[i] = P.leaves[i].v; }
-        device_unpack_leaves(H, (int64_t)ids.size(), ids.data(), uo.data(), vo.data(), f->factor);
+        std::vector<int64_t> uo(sel.size()), vo(sel.size());
+        for (size_t i = 0; i < sel.size(); i++) { uo[i] = P.leaves[i].u; vo[i] = P.leaves[i].v; }
+        device_unpack_leaves(H, (int64_t)sel.size(), sel.data(), uo.data(), vo.data(), f->factor);
     }
     const Ctx c0 = f->ctx(nullptr, nullptr, 0, 0);
     if (!mirrors.empty()) {
@@ -1115,6 +1157,7 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
     hlu_upload_solves(*f);
     long long counters[8];
     HIP_OK(hipMemcpy(counters, f->counters, sizeof(counters), hipMemcpyDeviceToHost));
+    if (symmetric) HM_CHECK(counters[4] == 0, kind == 1 ? "lu_factorization: the symmetric operator is not positive definite" : "cholesky_factorization: matrix is not positive definite");
     HM_CHECK(counters[4] == 0, kind == 1 ? "lu_factorization: singular matrix (zero pivot in a diagonal leaf)" : "cholesky_factorization: singular matrix (zero pivot in a diagonal leaf)");
     int64_t tasks = 0, launches = 0, rank_sum = 0, lr_rows = 0;
     for (const Program &w : P.factor) { tasks += (int64_t)w.tasks.size(); launches += (int64_t)w.buckets.size(); }
@@ -1133,7 +1176,7 @@ DeviceHLU *device_hlu_factor(const HMatrix &H, int kind, double shift, double ep
         log_message(LOG_WARNING, strprintf("hierarchical LU: %lld truncations were cut at the capacity of their leaf (accuracy below the asked %.1e: raise HTOOL_HLU_CAP_FACTOR, now %.2f)",
                                            counters[0], prm.eps, prm.cap_factor));
     log_message(LOG_INFO, strprintf("hierarchical %s of the %d x %d operator: plan %.3f s (%lld tasks, %lld launches, %d windows), leaves into the factor arena %.3f s, factorisation %.3f s; "
-                                    "factors %.2f GB resident (%.2f GB of arena and scratch while factorising), eps %.1e, mean rank %.1f", kind == 1 ? "LU" : "Cholesky (as LU)", P.n, P.n, f->seconds[0], (long long)tasks, (long long)launches,
+                                    "factors %.2f GB resident (%.2f GB of arena and scratch while factorising), eps %.1e, mean rank %.1f", symmetric ? (kind == 1 ? "LU by Cholesky (symmetric positive definite)" : "Cholesky") : (kind == 1 ? "LU" : "Cholesky (as LU)"), P.n, P.n, f->seconds[0], (long long)tasks, (long long)launches,
                                     (int)P.factor.size(), f->seconds[1], f->seconds[2], s[5] / 1e9, s[6] / 1e9, prm.eps, lr_rows ? (double)rank_sum / lr_rows : 0.0));
     // the programs of the factorisation are not needed any more (the solves are on the device)
     for (Program &w : f->plan->factor) { std::vector<Task>().swap(w.tasks); std::vector<int64_t>().swap(w.seg); }

@@ -118,6 +118,7 @@ struct Emitter {
             for (int b = 0; b < ncs; b++) {
                 const int ct = (split & 1) ? T.first_child[t] + a : t, cs = (split & 2) ? T.first_child[s] + b : s;
                 if (T.size[ct] == 0 || T.size[cs] == 0) continue;
+                if (P.params.symmetric && end(ct) <= T.offset[cs]) continue; // (strictly above the diagonal: not part of the factorisation)
                 const int c = build_bnode(ct, cs, leaf_of);
                 kid[k0 + a * ncs + b] = c;
             }
@@ -136,6 +137,18 @@ struct Emitter {
             if (B.split & 2) { if (s == B.s) return b; si = child_containing(B.s, s); }
             const int c = kid[B.kids + ti * ncs_of(B) + si];
             HM_CHECK(c >= 0, "hierarchical LU: empty block");
+            b = c;
+        }
+    }
+    int descend_soft(int b, int t, int s) const { // the same for a TARGET of the symmetric factorisation: blocks above the diagonal do not exist
+        for (;;) {
+            const BNode &B = bn[b];
+            if (B.leaf >= 0) return b;
+            int ti = 0, si = 0;
+            if (B.split & 1) { if (t == B.t) return b; ti = child_containing(B.t, t); }
+            if (B.split & 2) { if (s == B.s) return b; si = child_containing(B.s, s); }
+            const int c = kid[B.kids + ti * ncs_of(B) + si];
+            if (c < 0) return b;
             b = c;
         }
     }
@@ -623,6 +636,147 @@ struct Emitter {
             }
         }
     }
+    // ---- symmetric positive definite operators: A = L L^T on the lower triangle ----
+    // C(t, s) -= A(t, r) A'(s, r)^T with a covering (t, r), b covering (s, r) (both below the diagonal), c covering (t, s); of C only what
+    // lies on or below the diagonal exists
+    void mm_sym(int t, int r, int s, int a, int b, int c) {
+        if (T.size[t] == 0 || T.size[r] == 0 || T.size[s] == 0) return;
+        if (end(t) <= T.offset[s]) return; // strictly above the diagonal
+        a = descend(a, t, r);
+        b = descend(b, s, r);
+        c = descend_soft(c, t, s);
+        const BNode &A = bn[a], &B = bn[b];
+        const bool a_lr = A.leaf >= 0 && P.leaves[A.leaf].kind == 1, b_lr = B.leaf >= 0 && P.leaves[B.leaf].kind == 1;
+        if (a_lr) { // (U_a V_a^T) B^T = U_a (B V_a)^T
+            begin_group();
+            const int la = A.leaf;
+            ensure_final(la);
+            Thin Z = new_scratch(s, P.leaves[la].cap);
+            fill_zero(Z, s, la, 0);
+            const Thin Va = leaf_v(la), Ua = leaf_u(la);
+            for_leaves(b, s, r, [&](int l, int it, int is) { apply_leaf(l, it, is, false, Va, Z, la, 0, true, false); });
+            for_leaves(c, t, s, [&](int l, int it, int is) { add_lr(l, it, is, Ua, Z, la, 0); });
+            return;
+        }
+        if (b_lr) { // A (U_b V_b^T)^T = (A V_b) U_b^T
+            begin_group();
+            const int lb = B.leaf;
+            ensure_final(lb);
+            Thin X = new_scratch(t, P.leaves[lb].cap);
+            fill_zero(X, t, lb, 0);
+            const Thin Ub = leaf_u(lb), Vb = leaf_v(lb);
+            for_leaves(a, t, r, [&](int l, int it, int is) { apply_leaf(l, it, is, false, Vb, X, lb, 0, true, false); });
+            for_leaves(c, t, s, [&](int l, int it, int is) { add_lr(l, it, is, X, Ub, lb, 0); });
+            return;
+        }
+        if (A.leaf >= 0 && B.leaf >= 0) { // two dense leaves (t x r) and (s x r)
+            begin_group();
+            const Leaf &LA = P.leaves[A.leaf], &LB = P.leaves[B.leaf];
+            const BNode &C = bn[c];
+            HM_CHECK(C.leaf >= 0, "hierarchical Cholesky: the target of a product of dense leaves is not a leaf");
+            Thin Da = leaf_u(A.leaf), Db = leaf_u(B.leaf); // D_b as it is: rows = the positions of s
+            if (P.leaves[C.leaf].kind == 0) { add_lr(C.leaf, t, s, Da, Db, -1, LA.n); return; }
+            const int kp = std::min(LA.m, LB.m);
+            Thin X = new_scratch(t, kp), Z = new_scratch(s, kp);
+            const int64_t w = scratch_used;
+            scratch_used += ((int64_t)LA.m * LB.m + 1) & ~(int64_t)1;
+            Task tk = blank(T_DDPROD);
+            tk.leaf = C.leaf;
+            tk.flags = F_TRANS;
+            tk.kref = (int)next_slot++;
+            tk.kconst = kp;
+            tk.m = LA.m; tk.n = LB.m; tk.r0 = LA.n;
+            tk.a = make_ref(SP_FACTOR, LA.u); tk.a_ld = LA.m;
+            tk.b = make_ref(SP_FACTOR, LB.u); tk.b_ld = LB.m;
+            tk.x = ref(X, T.offset[t]); tk.x_ld = X.ld;
+            tk.y = ref(Z, T.offset[s]); tk.y_ld = Z.ld;
+            tk.w = make_ref(SP_SCRATCH, w);
+            const int lev = emit(tk, std::max(dep_leaf_read(A.leaf), dep_leaf_read(B.leaf)));
+            note_leaf_read(A.leaf, lev);
+            note_leaf_read(B.leaf, lev);
+            X.tr->note_write(cell0[t], cell1[t], lev);
+            Z.tr->note_write(cell0[s], cell1[s], lev);
+            add_lr(C.leaf, t, s, X, Z, tk.kref, 0);
+            return;
+        }
+        const bool st = A.leaf < 0 && (A.split & 1) && t == A.t;
+        const bool sr = (A.leaf < 0 && (A.split & 2) && r == A.s) || (B.leaf < 0 && (B.split & 2) && r == B.s);
+        const bool ss = B.leaf < 0 && (B.split & 1) && s == B.t;
+        HM_CHECK(st || sr || ss, "hierarchical Cholesky: the product recursion cannot descend");
+        HM_CHECK((!st || T.n_child[t] > 0) && (!sr || T.n_child[r] > 0) && (!ss || T.n_child[s] > 0), "hierarchical Cholesky: split of a cluster leaf");
+        const int nt = st ? T.n_child[t] : 1, nr = sr ? T.n_child[r] : 1, ns = ss ? T.n_child[s] : 1;
+        for (int i = 0; i < nt; i++)
+            for (int k = 0; k < nr; k++)
+                for (int j = 0; j < ns; j++)
+                    mm_sym(st ? T.first_child[t] + i : t, sr ? T.first_child[r] + k : r, ss ? T.first_child[s] + j : s, a, b, c);
+    }
+    // B(t, s) <- B(t, s) L(s,s)^-T   (t below s)
+    void solve_lt_sym(int t, int s, int b) {
+        if (T.size[t] == 0 || T.size[s] == 0) return;
+        b = descend(b, t, s);
+        const BNode &B = bn[b];
+        HM_CHECK(B.t == t && B.s == s, "hierarchical Cholesky: a triangular solve met a block that is not a node of the block tree");
+        if (B.leaf >= 0) {
+            const Leaf &L = P.leaves[B.leaf];
+            if (L.kind == 1) { // V <- L^-1 V
+                ensure_final(B.leaf);
+                Thin X = leaf_v(B.leaf);
+                X.opleaf = -1; X.tr = &trV[B.leaf];
+                thin_solve_l(s, X, B.leaf, 0);
+            } else { // D <- D L^-T: the rows of D, in place
+                const int ld = bn[diag_bnode[s]].leaf;
+                const Diag &D = P.diags[P.leaves[ld].diag];
+                Task tk = blank(T_APPLY_DENSE);
+                tk.leaf = ld;
+                tk.flags = F_INPLACE | F_XT | F_YT;
+                tk.kref = -1; tk.kconst = L.m;
+                tk.m = tk.n = D.m;
+                tk.a = make_ref(SP_DIAG, D.linv); tk.a_ld = D.m;
+                tk.x = tk.y = make_ref(SP_FACTOR, L.u); tk.x_ld = tk.y_ld = L.m;
+                const int dep = std::max(trD[P.leaves[ld].diag].dep_read_all(), trU[B.leaf].dep_write_all());
+                const int lev = emit(tk, dep);
+                trD[P.leaves[ld].diag].note_read_all(lev);
+                trU[B.leaf].note_write_all(lev);
+            }
+            return;
+        }
+        const int nt = (B.split & 1) ? T.n_child[t] : 1;
+        for (int i = 0; i < nt; i++) {
+            const int ti = (B.split & 1) ? T.first_child[t] + i : t;
+            if (!(B.split & 2)) { solve_lt_sym(ti, s, b); continue; }
+            const int nc = T.n_child[s], f = T.first_child[s];
+            for (int j = 0; j < nc; j++) {
+                solve_lt_sym(ti, f + j, b);
+                for (int j2 = j + 1; j2 < nc; j2++) mm_sym(ti, f + j, f + j2, b, diag_bnode[s], b);
+            }
+        }
+    }
+    void chol(int t) {
+        if (T.size[t] == 0) return;
+        const int d = diag_bnode[t];
+        HM_CHECK(d >= 0, "hierarchical Cholesky: a diagonal block is missing");
+        if (bn[d].leaf >= 0) {
+            const int l = bn[d].leaf;
+            const Leaf &L = P.leaves[l];
+            HM_CHECK(L.kind == 0 && L.diag >= 0, "hierarchical Cholesky: a diagonal leaf is not dense");
+            Task tk = blank(T_GETRF);
+            tk.leaf = l;
+            tk.flags = F_SYM;
+            tk.m = tk.n = L.m;
+            const int lev = emit(tk, std::max(trU[l].dep_write_all(), trD[L.diag].dep_write_all()));
+            trU[l].note_write_all(lev);
+            trD[L.diag].note_write_all(lev);
+            return;
+        }
+        const int nc = T.n_child[t], f = T.first_child[t];
+        for (int i = 0; i < nc; i++) {
+            if (T.size[f + i] == 0) continue;
+            chol(f + i);
+            for (int j = i + 1; j < nc; j++) solve_lt_sym(f + j, f + i, d);
+            for (int j = i + 1; j < nc; j++)
+                for (int k = i + 1; k <= j; k++) mm_sym(f + j, f + i, f + k, d, d, d);
+        }
+    }
     void lu(int t) {
         if (T.size[t] == 0) return;
         const int d = diag_bnode[t];
@@ -750,7 +904,8 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
     // window 0: every low-rank leaf is truncated once (ranks of the compression -> ranks of the arithmetic; norms)
     for (size_t i = 0; i < in.size(); i++) if (P.leaves[i].kind == 1) { E.dirty[i] = 1; E.ensure_final((int)i); }
     E.close_window();
-    E.lu(root);
+    if (prm.symmetric) E.chol(root);
+    else E.lu(root);
     for (size_t i = 0; i < in.size(); i++) E.ensure_final((int)i);
     E.close_window();
     P.n_slots = E.next_slot;
@@ -768,7 +923,8 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
         X.base = 0; X.ld = -1; X.pos0 = P.pos0; X.space = SP_RHS; X.tr = &rhs;
         int64_t keep[T_NTYPES];
         for (int q = 0; q < T_NTYPES; q++) keep[q] = P.counts[q];
-        if (pass == 0) { E.thin_solve_l(root, X, -2, 0); E.thin_solve_u(root, X, -2, 0); }
+        if (prm.symmetric) { E.thin_solve_l(root, X, -2, 0); E.thin_solve_lt(root, X, -2, 0); } // A = L L^T: the same sweeps for A and A^T
+        else if (pass == 0) { E.thin_solve_l(root, X, -2, 0); E.thin_solve_u(root, X, -2, 0); }
         else { E.thin_solve_ut(root, X, -2, 0); E.thin_solve_lt(root, X, -2, 0); }
         for (int q = 0; q < T_NTYPES; q++) P.counts[q] = keep[q];
         E.finish_program(E.cur, pass == 0 ? P.solve_n : P.solve_t);

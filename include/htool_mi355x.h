@@ -375,7 +375,8 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
  * block-recursive algorithm is run once on the host on the block structure alone and turned into levels of leaf tasks
  * (csrc/hlu_symbolic.cpp, csrc/hlu.hpp).  The entries below expose that PLAN for tests: rects5 = (t_off, m, s_off, n, rank) per leaf
  * of a square operator on the cluster tree of `root`, rank < 0 for a dense leaf; the plan is host data only (no device needed).
- * htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
+ * cap_factor < 0: the operator is symmetric positive definite and rects5 holds its LOWER triangle only (diagonal leaves included): the plan
+ * is the hierarchical Cholesky factorisation A = L L^T.  htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
  * each, struct hm::hlu::Task), launch buckets and target runs of one window of the factorisation (which >= 0) or of the
  * solves (-1: 'N', -2: 'T'); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
 /* what htool_hmatrix_lu_factorization / _cholesky_factorization left behind: out17[0] = 0 nothing, 1 dense on the host, 2 dense on

@@ -18,7 +18,7 @@
 namespace {
 
 enum { T_FILL = 0, T_APPLY_DENSE = 1, T_APPLY_LR = 2, T_ADDLR = 3, T_FINAL = 4, T_DDPROD = 5, T_GETRF = 6 };
-enum { F_TRANS = 1, F_INPLACE = 2, F_ACCUM = 4, F_SUB = 8, F_XT = 16, F_YT = 32 };
+enum { F_TRANS = 1, F_INPLACE = 2, F_ACCUM = 4, F_SUB = 8, F_XT = 16, F_YT = 32, F_SYM = 64 };
 struct Task {
     int32_t type, flags, level, leaf, kref, kconst, m, n, r0, c0, a_ld, b_ld, x_ld, y_ld;
     int64_t a, b, x, y, w;
@@ -255,7 +255,8 @@ void run_task(State &S, const Task &t) {
         for (int j = 0; j < n; j++)
             for (int i = 0; i < m; i++) {
                 double s = 0;
-                for (int l = 0; l < q; l++) s += A[i + (int64_t)l * t.a_ld] * B[l + (int64_t)j * t.b_ld];
+                if (t.flags & F_TRANS) for (int l = 0; l < q; l++) s += A[i + (int64_t)l * t.a_ld] * B[j + (int64_t)l * t.b_ld]; // (b is n x q: a b^T)
+                else for (int l = 0; l < q; l++) s += A[i + (int64_t)l * t.a_ld] * B[l + (int64_t)j * t.b_ld];
                 W[i + (int64_t)j * m] = s;
             }
         // cross approximation with full pivoting on the explicit residual, until its Frobenius norm is below the tolerance
@@ -292,7 +293,8 @@ void run_task(State &S, const Task &t) {
         std::vector<int> piv(m);
         for (int j = 0; j < m; j++) {
             int p = j;
-            for (int i = j + 1; i < m; i++) if (std::fabs(A[i + (int64_t)j * m]) > std::fabs(A[p + (int64_t)j * m])) p = i;
+            if (!(t.flags & F_SYM)) { for (int i = j + 1; i < m; i++) if (std::fabs(A[i + (int64_t)j * m]) > std::fabs(A[p + (int64_t)j * m])) p = i; }
+            else if (!(A[j + (int64_t)j * m] > 0)) S.counters[4]++; // (a symmetric positive definite leaf needs no pivoting: L U with U = D L^T)
             piv[j] = p;
             if (p != j) for (int c = 0; c < m; c++) std::swap(A[j + (int64_t)c * m], A[p + (int64_t)c * m]);
             const double d = A[j + (int64_t)j * m];
@@ -316,6 +318,10 @@ void run_task(State &S, const Task &t) {
                 for (int i = 0; i < j; i++) z[i] -= A[i + (int64_t)j * m] * z[j];
             }
             for (int i = 0; i < m; i++) Ui[i + (int64_t)c * m] = z[i];
+        }
+        if (t.flags & F_SYM) { // the inverse of the CHOLESKY factor L_c = L D^(1/2): rows of L^-1 scaled by 1 / sqrt(d), and its transpose
+            for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) Li[i + (int64_t)c * m] /= std::sqrt(A[i + (int64_t)i * m]);
+            for (int c = 0; c < m; c++) for (int i = 0; i < m; i++) Ui[i + (int64_t)c * m] = Li[c + (int64_t)i * m];
         }
         break;
     }

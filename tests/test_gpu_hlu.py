@@ -31,12 +31,15 @@ def device_solve(plan, state, B, trans="N"):
     return X[:, 0] if np.ndim(B) == 1 else X
 
 
-@pytest.mark.parametrize("n,leaf,eta,children", [(260, 40, 1e-4, 2), (900, 30, 10.0, 2), (700, 25, 10.0, 3), (1500, 60, 3.0, 2)])
-def test_device_kernels_match_the_cpu_checker_window_by_window(n, leaf, eta, children):
+@pytest.mark.parametrize("n,leaf,eta,children,sym", [(260, 40, 1e-4, 2, False), (900, 30, 10.0, 2, False), (700, 25, 10.0, 3, False), (1500, 60, 3.0, 2, False),
+                                                     (260, 40, 1e-4, 2, True), (900, 30, 10.0, 2, True), (700, 25, 10.0, 3, True)])
+def test_device_kernels_match_the_cpu_checker_window_by_window(n, leaf, eta, children, sym):
+    """sym: the hierarchical Cholesky factorisation of the lower triangle (Params::symmetric)."""
     eps, eps_lu = 1e-3, 1e-4
     H, cl = make_case(n, leaf, eps, eta, children)
-    plan = Htool.HLUPlan(cl, H.leaves, eps_lu, window_tasks=2000, cap_factor=2.5 * np.log(eps_lu) / np.log(eps))
-    host = ohlu.HostLU(plan, H.leaf_data, eps_lu, run=False)
+    ids = np.where(H.leaves[:, 0] >= H.leaves[:, 2])[0] if sym else np.arange(len(H.leaves))
+    plan = Htool.HLUPlan(cl, H.leaves[ids], eps_lu, window_tasks=2000, symmetric=sym)
+    host = ohlu.HostLU(plan, lambda i: H.leaf_data(int(ids[i])), eps_lu, run=False)
     n_win = host.info["windows"]
     n_leaves = host.n_leaves   # (the records behind the operator's leaves are the stage blocks of split update runs)
     lr = host.leaves["kind"][:n_leaves] == 1
@@ -60,12 +63,14 @@ def test_device_kernels_match_the_cpu_checker_window_by_window(n, leaf, eta, chi
         assert dev.counters[4] == 0
 
 
-@pytest.mark.parametrize("n,leaf,eta", [(1000, 30, 10.0), (3000, 50, 10.0)])
-def test_device_factorisation_solves_the_system(n, leaf, eta):
+@pytest.mark.parametrize("n,leaf,eta,sym", [(1000, 30, 10.0, False), (3000, 50, 10.0, False), (3000, 50, 10.0, True)])
+def test_device_factorisation_solves_the_system(n, leaf, eta, sym):
     eps, eps_lu = 1e-3, 1e-4
     H, cl = make_case(n, leaf, eps, eta)
-    plan = Htool.HLUPlan(cl, H.leaves, eps_lu, cap_factor=2.5 * np.log(eps_lu) / np.log(eps))
-    st = ohlu.HostLU(plan, H.leaf_data, eps_lu, run=False)
+    ids = np.where(H.leaves[:, 0] >= H.leaves[:, 2])[0] if sym else np.arange(len(H.leaves))
+    plan = Htool.HLUPlan(cl, H.leaves[ids], eps_lu, symmetric=sym)
+    leaf_data = lambda i: H.leaf_data(int(ids[i]))  # noqa: E731
+    st = ohlu.HostLU(plan, leaf_data, eps_lu, run=False)
     plan.debug_execute(0, st.info["windows"] - 1, st.factor, st.diag, st.rank, st.norm0, st.norm2, st.counters)
     assert st.counters[0] <= 0.02 * st.counters[1] and st.counters[4] == 0   # (truncations cut at a leaf's capacity: rare)
     A = H.to_dense()
@@ -80,7 +85,7 @@ def test_device_factorisation_solves_the_system(n, leaf, eta):
     Xt = device_solve(plan, st, B, "T")
     assert np.linalg.norm(Xt - np.linalg.solve(A.T, B)) / np.linalg.norm(Xd) < bar
     # bitwise reproducible: the same plan on the same data gives the same factors
-    st2 = ohlu.HostLU(plan, H.leaf_data, eps_lu, run=False)
+    st2 = ohlu.HostLU(plan, leaf_data, eps_lu, run=False)
     plan.debug_execute(0, st2.info["windows"] - 1, st2.factor, st2.diag, st2.rank, st2.norm0, st2.norm2, st2.counters)
     assert np.array_equal(st.diag, st2.diag) and np.array_equal(st.ranks(), st2.ranks())
     assert np.array_equal(device_solve(plan, st2, B), X)
@@ -129,6 +134,8 @@ def test_lu_factorization_of_an_operator_is_hierarchical_and_solves(built, n, le
     Hd = copy.deepcopy(H)
     Hd.cholesky_factorization("L")
     assert Hd.factorization_info()["kind"] == "hierarchical"
+    if sym[0] == "N":   # (the LU of the 'N' operator above against the Cholesky factorisation of its lower triangle: about half the tasks)
+        assert Hd.factorization_info()["tasks"] < 0.7 * info["tasks"]
     xc = Hd.cholesky_solve("L", H * x_ref)
     assert np.linalg.norm(xc - x_ref) / np.linalg.norm(x_ref) < eps
     with pytest.raises(RuntimeError, match="lu_factorization first"):
@@ -219,3 +226,19 @@ def test_hierarchical_lu_of_the_per_gpu_block_of_c5(built, oracle):
     sinfo = solver.get_information()
     assert "hierarchical" in sinfo["Preconditioner"] and int(sinfo["Nb_it"]) <= 8, sinfo
     assert np.linalg.norm(xs - x_ref) / np.linalg.norm(x_ref) < 1e-6
+
+
+def test_symmetric_operator_that_is_not_positive_definite_falls_back_to_the_lu(built):
+    """lu_factorization of an 'S' operator tries the hierarchical Cholesky factorisation first; a negative shift makes the operator
+    indefinite: the attempt reports it and the LU takes over."""
+    n, eps = 3000, 1e-4
+    pts, cl, H = _operator(n, 40, eps, ("S", "L"))
+    A = np.asarray(H.to_dense_in_user_numbering())
+    lam = np.linalg.eigvalsh(A)
+    shift = -0.5 * (lam[-1] + lam[-2])                      # between the two largest eigenvalues: one positive, the others negative, far from singular
+    H.lu_factorization_shifted(float(shift))
+    assert H.factorization_info()["kind"] == "hierarchical"
+    B = np.random.default_rng(2).normal(size=(n, 2))
+    X = H.lu_solve("N", np.asfortranarray(B))
+    Xd = np.linalg.solve(A + shift * np.eye(n), B)
+    assert np.linalg.norm(X - Xd) / np.linalg.norm(Xd) < 1e-5

@@ -84,3 +84,26 @@ def test_long_update_runs_are_split_over_stage_blocks():
     other = ohlu.HostLU(split, H.leaf_data, eps_lu, shuffle=3)
     assert np.array_equal(lu.factor, other.factor)  # the parts of a run and their merge are ordered by the plan, not by the schedule
     assert info["leaves"] == len(H.leaves)
+
+
+@pytest.mark.parametrize("n,leaf,children", [(900, 30, 2), (700, 25, 3), (1600, 50, 2)])
+def test_symmetric_plan_is_a_hierarchical_cholesky(n, leaf, children):
+    """Params::symmetric: the lower triangle only, A = L L^T; half the tasks of the LU, the same solution."""
+    eps, eps_lu = 1e-3, 1e-4
+    H, cl = make_case(n, leaf, eps, 10.0, children)
+    lower = np.where(H.leaves[:, 0] >= H.leaves[:, 2])[0]
+    plan = Htool.HLUPlan(cl, H.leaves[lower], eps_lu, symmetric=True)
+    full = Htool.HLUPlan(cl, H.leaves, eps_lu)
+    assert plan.info()[8] < 0.7 * full.info()[8]           # tasks
+    lu = ohlu.HostLU(plan, lambda i: H.leaf_data(int(lower[i])), eps_lu)
+    assert lu.counters[4] == 0                              # positive definite
+    A = H.to_dense()
+    B = np.random.default_rng(4).normal(size=(n, 3))
+    Xd = np.linalg.solve(A, B)
+    bar = 5 * eps_lu * max(1.0, np.sqrt(np.linalg.cond(A)) / 10)
+    assert np.linalg.norm(lu.solve(B) - Xd) / np.linalg.norm(Xd) < bar
+    assert np.linalg.norm(lu.solve(B, "T") - Xd) / np.linalg.norm(Xd) < bar
+    x = lu.solve(A @ np.ones(n))
+    assert np.linalg.norm(x - 1) / np.sqrt(n) < eps
+    other = ohlu.HostLU(plan, lambda i: H.leaf_data(int(lower[i])), eps_lu, shuffle=7)
+    assert np.array_equal(lu.factor, other.factor) and np.array_equal(lu.diag, other.diag)

@@ -35,9 +35,9 @@ b = Htool.ClusterTreeBuilder()
 b.set_maximal_leaf_size(leaf)
 gen = Htool.NativeGenerator("inv_delta", pts, pts, 0.1)
 t0 = time.time()
-if mode == "1":
+if mode in ("1", "1S"):   # "1S": the block declared symmetric -- factorised as A = L L^T on its lower triangle
     cl = b.create_cluster_tree(pts, 2, size_of_partition=8)
-    H = Htool.HMatrixTreeBuilder(eps, 10.0, "N", "N").build_local(gen, cl, cl, 3, 3)
+    H = Htool.HMatrixTreeBuilder(eps, 10.0, *(("S", "L") if mode == "1S" else ("N", "N"))).build_local(gen, cl, cl, 3, 3)
 else:
     cl = b.create_cluster_tree(pts, 2, 2)
     H = Htool.HMatrixTreeBuilder(eps, 10.0, *(("S", "L") if mode == "S" else ("N", "N"))).build(gen, cl, cl)
