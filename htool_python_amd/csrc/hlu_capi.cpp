@@ -34,7 +34,7 @@ std::vector<LeafIn> leaves_from_rects(const ClusterTree &T, int64_t n, const int
 extern "C" {
 
 int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int32_t *rects5, double epsilon, int cap_min, int cap_max, double cap_factor,
-                          int64_t window_scratch_elems, int64_t window_tasks, htool_hlu_plan **out) {
+                          int64_t window_scratch_elems, int64_t window_tasks, int symmetric, htool_hlu_plan **out) {
     API_BEGIN
     HM_CHECK(root && rects5 && out, "htool_hlu_plan_create: null argument");
     const ClusterHandle *h = reinterpret_cast<const ClusterHandle *>(root);
@@ -45,7 +45,7 @@ int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int
     if (cap_factor > 0) P.cap_factor = cap_factor;
     if (window_scratch_elems > 0) P.window_scratch_elems = window_scratch_elems;
     if (window_tasks > 0) P.window_tasks = window_tasks;
-    if (cap_factor < 0) { P.symmetric = true; } // (diagnostic entry: a negative capacity factor asks for the symmetric factorisation of the given lower triangle)
+    P.symmetric = symmetric != 0;
     std::vector<hlu::LeafIn> in = hlu::leaves_from_rects(*h->tree, n_leaves, rects5);
     htool_hlu_plan *p = new htool_hlu_plan;
     try { p->plan = hlu::make_plan(*h->tree, in, P, h->node); } catch (...) { delete p; throw; }

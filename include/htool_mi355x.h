@@ -375,7 +375,7 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
  * block-recursive algorithm is run once on the host on the block structure alone and turned into levels of leaf tasks
  * (csrc/hlu_symbolic.cpp, csrc/hlu.hpp).  The entries below expose that PLAN for tests: rects5 = (t_off, m, s_off, n, rank) per leaf
  * of a square operator on the cluster tree of `root`, rank < 0 for a dense leaf; the plan is host data only (no device needed).
- * cap_factor < 0: the operator is symmetric positive definite and rects5 holds its LOWER triangle only (diagonal leaves included): the plan
+ * symmetric != 0: the operator is symmetric positive definite and rects5 holds its LOWER triangle only (diagonal leaves included): the plan
  * is the hierarchical Cholesky factorisation A = L L^T.  htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
  * each, struct hm::hlu::Task), launch buckets and target runs of one window of the factorisation (which >= 0) or of the
  * solves (-1: 'N', -2: 'T'); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
@@ -387,7 +387,7 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
 int htool_hmatrix_factorization_info(const htool_hmatrix *h, int64_t *out17, double *seconds4);
 typedef struct htool_hlu_plan htool_hlu_plan;
 int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int32_t *rects5, double epsilon, int cap_min, int cap_max, double cap_factor,
-                          int64_t window_scratch_elems, int64_t window_tasks, htool_hlu_plan **out);
+                          int64_t window_scratch_elems, int64_t window_tasks, int symmetric, htool_hlu_plan **out);
 int htool_hlu_plan_info(const htool_hlu_plan *plan, int64_t *out, int n_out);
 int htool_hlu_plan_program(const htool_hlu_plan *plan, int which, const void **tasks, int64_t *n_tasks, const void **buckets, int64_t *n_buckets,
                            const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems);

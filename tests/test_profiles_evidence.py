@@ -65,7 +65,8 @@ def test_bench_line_agrees_with_the_rocprof_summary():
 
 def test_hierarchical_lu_evidence_is_consistent():
     """profiles/r04_hlu_*.json (tools/hlu_bench.py): hierarchical factorisations, far below a dense copy in memory, solving their system."""
-    for name, unknowns in (("r04_hlu_12k.json", 12000), ("r04_hlu_c5_block_62500.json", 62500), ("r04_hlu_250k_symmetric_shifted.json", 250000)):
+    for name, unknowns in (("r04_hlu_12k.json", 12000), ("r04_hlu_c5_block_62500.json", 62500), ("r04_hlu_250k_symmetric_shifted.json", 250000),
+                           ("r04_hlu_250k_symmetric_cholesky.json", 250000), ("r04_hlu_500k_symmetric_cholesky.json", 500000), ("r04_hlu_500k_symmetric_shifted.json", 500000)):
         d = _line(name)
         info = d["info"]
         assert d["unknowns"] == unknowns and info["kind"] == "hierarchical" and info["unknowns"] == unknowns
