@@ -638,16 +638,21 @@ __global__ __launch_bounds__(256) void hlu_getrf_lds_kernel(Ctx c, const Task *t
     for (int j = 0; j < m; j++) {
         double best = -1.0;
         int bi = j;
-        if (!sym) for (int i = j + tid; i < m; i += 256) { const double v = fabs(As[i + j * m]); if (v > best) { best = v; bi = i; } }
-        else if (tid == 0) best = As[j + j * m] > 0 ? 1.0 : 0.0;
-        rbest[tid] = best; ridx[tid] = bi;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s && (rbest[tid + s] > rbest[tid] || (rbest[tid + s] == rbest[tid] && ridx[tid + s] < ridx[tid]))) { rbest[tid] = rbest[tid + s]; ridx[tid] = ridx[tid + s]; }
+        int p = j;
+        if (!sym) {
+            for (int i = j + tid; i < m; i += 256) { const double v = fabs(As[i + j * m]); if (v > best) { best = v; bi = i; } }
+            rbest[tid] = best; ridx[tid] = bi;
             __syncthreads();
+            for (int s = 128; s > 0; s >>= 1) {
+                if (tid < s && (rbest[tid + s] > rbest[tid] || (rbest[tid + s] == rbest[tid] && ridx[tid + s] < ridx[tid]))) { rbest[tid] = rbest[tid + s]; ridx[tid] = ridx[tid + s]; }
+                __syncthreads();
+            }
+            p = ridx[0];
+            if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) atomicAdd((unsigned long long *)&c.counters[4], 1ull); }
+        } else if (tid == 0) { // (no pivot search, none of its barriers: the diagonal entry must be positive)
+            piv[j] = j;
+            if (!(As[j + j * m] > 0)) atomicAdd((unsigned long long *)&c.counters[4], 1ull);
         }
-        const int p = sym ? j : ridx[0];
-        if (tid == 0) { piv[j] = p; if (rbest[0] == 0.0) atomicAdd((unsigned long long *)&c.counters[4], 1ull); }
         __syncthreads();
         if (p != j) for (int col = tid; col < m; col += 256) { const double a = As[j + col * m]; As[j + col * m] = As[p + col * m]; As[p + col * m] = a; }
         __syncthreads();
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(256) void hlu_getrf_lds_kernel(Ctx c, const Task *t
             Bs[pos + cc * m] = 1.0;
         }
         __syncthreads();
-        for (int j = 0; j < m; j++) {
+        for (int j = sym ? c0 : 0; j < m; j++) { // (without a permutation the columns from c0 on are zero above row c0)
             const int nn = m - j - 1;
             for (int e = tid; e < nn * w; e += 256) { const int i = j + 1 + e % nn, cc = e / nn; Bs[i + cc * m] -= As[i + j * m] * Bs[j + cc * m]; }
             __syncthreads();
