@@ -1062,6 +1062,10 @@ static DeviceHLU *hlu_factor_impl(const HMatrix &H, int kind, double shift, doub
     prm.cap_factor = 2.5 * std::max(1.0, std::log(prm.eps) / std::log(eb)); // (measured: the ranks of the factors reach 2.5-3 x those of the operator at a tenth of its tolerance)
     if (const char *e = getenv("HTOOL_HLU_CAP_FACTOR")) if (atof(e) > 0) prm.cap_factor = atof(e);
     if (const char *e = getenv("HTOOL_HLU_WINDOW_MB")) if (atof(e) > 0) prm.window_scratch_elems = (int64_t)(atof(e) * 1e6 / 8);
+    if (const char *e = getenv("HTOOL_HLU_SPLIT")) { // "min,part,max": how long runs of updates of one leaf are dealt out (hlu.hpp: Params::split_*)
+        int a = 0, b = 0, c3 = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c3) == 3 && a >= 1 && b >= 1 && c3 >= 1) { prm.split_min = a; prm.split_part = b; prm.split_max_parts = c3; }
+    }
     std::unique_ptr<DeviceHLU> f(new DeviceHLU);
     f->plan = make_plan(T, in, prm, H.t_root);
     const Plan &P = *f->plan;
