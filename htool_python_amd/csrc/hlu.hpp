@@ -28,7 +28,13 @@ namespace hm {
 namespace hlu {
 
 // ---- plain records shared by the host plan, the device executor and the CPU checker under oracle/ ----
-enum TaskType : int32_t { T_FILL = 0, T_APPLY_DENSE = 1, T_APPLY_LR = 2, T_ADDLR = 3, T_FINAL = 4, T_DDPROD = 5, T_GETRF = 6, T_NTYPES = 7 };
+enum TaskType : int32_t { T_FILL = 0, T_APPLY_DENSE = 1, T_APPLY_LR = 2, T_ADDLR = 3, T_FINAL = 4, T_DDPROD = 5, T_GETRF = 6, T_REDUCE = 7, T_NTYPES = 8 };
+// T_REDUCE (solve programs): Y[rows of one cluster leaf] -= the sum, in the order of the list, of kconst private contributions (entries a ... of the program's
+// aux list: a space-tagged reference and a leading dimension each).  A triangular sweep subtracts, at every node of the cluster tree, the product of an
+// off-diagonal block with the part of the solution that is known: the leaves of that block overlap in their rows, and subtracting them one after the
+// other is a chain of dependent launches (a dozen per node at the upper levels of the tree).  Instead every leaf writes its product into a slot of its own -- all
+// of them side by side in one launch -- and one REDUCE task per cluster leaf sums them in a fixed order: two launches per node, bitwise reproducible.
+constexpr int SOLVE_SLOT_COLUMNS = 8; // columns of right-hand sides a slot holds: a solve with more runs in chunks
 enum TaskFlags : int32_t {
     F_TRANS = 1,     // APPLY_DENSE: M^T;  APPLY_LR: the leaf transposed (roles of U and V exchanged -- already folded into a / b)
     F_INPLACE = 2,   // APPLY_DENSE: Y is X (square M), Y = M X
@@ -36,6 +42,7 @@ enum TaskFlags : int32_t {
     F_SUB = 8,       // alpha = -1
     F_XT = 16,       // x is a transposed view: element (i, c) at x + i * x_ld + c  (otherwise x + i + c * x_ld)
     F_YT = 32,       // the same for y
+    F_IDENT = 128,   // FILL: the identity (the entry (i, i) of column i is one) instead of zeros
     F_SYM = 64,      // GETRF: the leaf is symmetric positive definite -- no pivoting, and the inverse factors are those of its CHOLESKY factor (L_c^-1 and its transpose)
 };
 // where an element offset points (top bits of a 64-bit reference)
@@ -69,11 +76,17 @@ static_assert(sizeof(Leaf) == 48, "leaf record layout");
 
 struct Diag { int32_t leaf, m; int64_t linv, uinv; }; // element offsets in the diagonal arena: (P L)^-1 and U^-1, m x m each
 
+// A diagonal block of at most Params::super_rows rows whose inverse factors are formed explicitly after the factorisation (m x m each, in the
+// diagonal arena): a triangular sweep is a SEQUENCE of dependent steps, one per cluster leaf and per tree node (~1600 per sweep at 62 500
+// unknowns, ~30 us each); with the sweep inside such a block replaced by one dense product the sequence is 8-16 times shorter.
+struct Super { int32_t node, m; int64_t linv, uinv; };
+
 struct Bucket { int32_t type, level; int64_t begin, end; int64_t seg_begin, seg_end; };
 
 struct Program {
     std::vector<Task> tasks;       // sorted by (level, type, [target leaf,] emission order)
     std::vector<Bucket> buckets;   // one batched launch each
+    std::vector<int64_t> aux;      // REDUCE tasks: (reference, leading dimension) of every contribution
     std::vector<int64_t> seg;      // ADDLR / FINAL buckets: first task of every run with one target (bucket.seg_begin .. seg_end, + one end marker per bucket)
     int64_t scratch_elems = 0;
     int n_levels = 0;
@@ -86,6 +99,8 @@ struct Params {
     double cap_factor = 2.5;                       // (ranks grow with the tolerance: the caller scales it by log(eps) / log(eps of the operator))
     int64_t window_scratch_elems = (int64_t)1 << 29; // a window of the task stream may hold this much scratch (4 GB of doubles)
     int64_t window_tasks = (int64_t)1 << 23;
+    int super_rows = 1024;  // solves: diagonal blocks of at most this many rows get explicit inverse factors (see Super; 0: none)
+    bool solve_slots = true; // solves: private slots + REDUCE tasks (see T_REDUCE); false: the leaves of a block subtract one after the other
     bool symmetric = false; // the operator is symmetric positive definite and only its LOWER triangle (diagonal leaves included) is given: H-Cholesky, A = L L^T
     int split_min = 8, split_part = 4, split_max_parts = 24; // a run of more than split_min updates of one low-rank leaf in one launch is dealt out to
                                                               // up to split_max_parts workgroups (>= split_part updates each), each with a stage block of its own
@@ -104,7 +119,9 @@ struct Plan {
     int64_t n_slots = 0;                                          // rank slots: leaves first, then the outputs of DDPROD tasks
     std::vector<Program> factor;                                  // the factorisation, window after window
     Program solve_n, solve_t;                                     // x <- A^-1 x and x <- A^-T x on an SP_RHS block
-    int64_t counts[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<Super> supers;                                    // diagonal blocks with explicit inverse factors ...
+    Program invert;                                               // ... and the program that forms them (run once, after the factorisation)
+    int64_t counts[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0, 0};
     double plan_seconds = 0;
 };
 

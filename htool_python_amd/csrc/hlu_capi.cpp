@@ -67,19 +67,19 @@ int htool_hlu_plan_info(const htool_hlu_plan *p, int64_t *out, int n_out) {
     v[6] = P.n_slots; v[7] = (int64_t)P.factor.size(); v[8] = tasks; v[9] = launches; v[10] = levels;
     v[11] = (int64_t)P.solve_n.tasks.size(); v[12] = (int64_t)P.solve_n.buckets.size(); v[13] = P.solve_n.n_levels;
     v[14] = (int64_t)(P.plan_seconds * 1e6); v[15] = (int64_t)P.solve_t.tasks.size();
-    for (int q = 0; q < hlu::T_NTYPES; q++) v[16 + q] = P.counts[q];
+    for (int q = 0; q < 7; q++) v[16 + q] = P.counts[q];
     for (int i = 0; i < n_out && i < 23; i++) out[i] = v[i];
     API_END
 }
 
-/* which >= 0: window of the factorisation, -1: solve 'N', -2: solve 'T'.  Pointers into the plan (valid until it is freed). */
+/* which >= 0: window of the factorisation, -1: solve 'N', -2: solve 'T', -3: the explicit inverse factors of the small diagonal blocks (run once after the windows).  Pointers into the plan (valid until it is freed). */
 int htool_hlu_plan_program(const htool_hlu_plan *p, int which, const void **tasks, int64_t *n_tasks, const void **buckets, int64_t *n_buckets,
-                           const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems) {
+                           const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems, const int64_t **aux, int64_t *n_aux) {
     API_BEGIN
     HM_CHECK(p && p->plan, "htool_hlu_plan_program: null argument");
     const hlu::Plan &P = *p->plan;
-    HM_CHECK(which >= -2 && which < (int)P.factor.size(), "htool_hlu_plan_program: no such program");
-    const hlu::Program &G = which == -1 ? P.solve_n : which == -2 ? P.solve_t : P.factor[(size_t)which];
+    HM_CHECK(which >= -3 && which < (int)P.factor.size(), "htool_hlu_plan_program: no such program");
+    const hlu::Program &G = which == -1 ? P.solve_n : which == -2 ? P.solve_t : which == -3 ? P.invert : P.factor[(size_t)which];
     if (tasks) *tasks = G.tasks.data();
     if (n_tasks) *n_tasks = (int64_t)G.tasks.size();
     if (buckets) *buckets = G.buckets.data();
@@ -87,6 +87,8 @@ int htool_hlu_plan_program(const htool_hlu_plan *p, int which, const void **task
     if (seg) *seg = G.seg.data();
     if (n_seg) *n_seg = (int64_t)G.seg.size();
     if (scratch_elems) *scratch_elems = G.scratch_elems;
+    if (aux) *aux = G.aux.data();
+    if (n_aux) *n_aux = (int64_t)G.aux.size();
     API_END
 }
 

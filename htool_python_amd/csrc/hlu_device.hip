@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256) void hlu_fill_kernel(Ctx c, const Task *tasks)
     const int q = cols_of(c, t);
     double *y = at(c, t.y);
     const long long ld = ld_of(c, t.y, t.y_ld);
+    const bool ident = t.flags & F_IDENT;
     for (long long e = threadIdx.x; e < (long long)q * t.m; e += 256) {
         const int col = (int)(e / t.m), i = (int)(e - (long long)col * t.m);
-        y[i + col * ld] = 0.0;
+        y[i + col * ld] = (ident && i == col) ? 1.0 : 0.0;
     }
 }
 
@@ -210,6 +211,21 @@ __global__ __launch_bounds__(256) void hlu_apply_kernel(Ctx c, const Task *tasks
     const Task t = tasks[blockIdx.x];
     if (t.type == T_APPLY_DENSE) apply_dense_body(c, t, sm);
     else apply_lr_body(c, t, W, red);
+}
+
+// (solve programs) Y[rows of one cluster leaf] -= the private contributions of the leaves of a block step, summed in the order of the list
+__global__ __launch_bounds__(256) void hlu_reduce_kernel(Ctx c, const Task *tasks, const long long *aux) {
+    const Task t = tasks[blockIdx.x];
+    const int q = cols_of(c, t);
+    double *y = at(c, t.y);
+    const long long yl = ld_of(c, t.y, t.y_ld);
+    const long long *list = aux + 2 * t.a;
+    for (int e = threadIdx.x; e < t.m * q; e += 256) {
+        const int i = e % t.m, col = e / t.m;
+        double s = 0;
+        for (int k = 0; k < t.kconst; k++) s += at(c, list[2 * k])[i + (long long)col * list[2 * k + 1]];
+        if (t.flags & F_SUB) y[i + col * yl] -= s; else y[i + col * yl] = s; // (without F_SUB: a copy back from a slot)
+    }
 }
 
 __device__ __forceinline__ int keep_max(const Leaf &L) { return L.cap - max(4, L.cap / 8); }
@@ -768,7 +784,7 @@ size_t update_lds_bytes(int Kc) { return std::max((size_t)(4 * Kc * (Kc + 1) + K
 
 struct DevProgram {
     Task *tasks = nullptr;
-    long long *seg = nullptr;
+    long long *seg = nullptr, *aux = nullptr;
     size_t n_tasks = 0, n_seg = 0;
 };
 
@@ -783,9 +799,9 @@ void attributes_once() {
 }
 
 // HTOOL_HLU_PROFILE=1: every launch is waited for and its time added up per task kind (printed by device_hlu_factor)
-double g_prof_seconds[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0};
-long long g_prof_launches[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0}, g_prof_items[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0};
-double g_prof_longest[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0};
+double g_prof_seconds[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0, 0};
+long long g_prof_launches[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0, 0}, g_prof_items[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0, 0};
+double g_prof_longest[T_NTYPES] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 // one program, bucket by bucket, on `st`; tasks / runs already on the device
 void run_program(const Program &G, const DevProgram &dp, const Ctx &c, const std::vector<Leaf> &leaves, hipStream_t st) {
@@ -837,6 +853,7 @@ void run_program(const Program &G, const DevProgram &dp, const Ctx &c, const std
             else hipLaunchKernelGGL(hlu_getrf_kernel, dim3(n), dim3(256), (size_t)mmax * sizeof(int), st, c, t0);
             break;
         }
+        case T_REDUCE: hipLaunchKernelGGL(hlu_reduce_kernel, dim3(n), dim3(256), 0, st, c, t0, dp.aux); break;
         default: throw Error("hierarchical LU: unknown task kind");
         }
         if (profile) {
@@ -882,12 +899,13 @@ struct DeviceHLU {
     double *norm0 = nullptr, *norm2 = nullptr;
     long long *counters = nullptr;
     DevProgram solve_n, solve_t;
+    double *solve_scratch = nullptr;
     int64_t stats[16] = {0};
     double seconds[4] = {0, 0, 0, 0}; // plan, unpack, factorisation, total
     ~DeviceHLU() {
         (void)hipSetDevice(device);
-        for (void *p : {(void *)factor, (void *)diag, (void *)leaves, (void *)diags, (void *)rank, (void *)norm0, (void *)norm2, (void *)counters, (void *)solve_n.tasks, (void *)solve_n.seg,
-                        (void *)solve_t.tasks, (void *)solve_t.seg})
+        for (void *p : {(void *)factor, (void *)diag, (void *)leaves, (void *)diags, (void *)rank, (void *)norm0, (void *)norm2, (void *)counters, (void *)solve_n.tasks, (void *)solve_n.seg, (void *)solve_n.aux,
+                        (void *)solve_t.tasks, (void *)solve_t.seg, (void *)solve_t.aux, (void *)solve_scratch})
             if (p) (void)hipFree(p);
         delete plan;
     }
@@ -971,11 +989,15 @@ void hlu_run_windows(DeviceHLU &f, int first, int last, hipStream_t st, double *
 
 void hlu_upload_solves(DeviceHLU &f) {
     const Plan &P = *f.plan;
+    const size_t slots = (size_t)std::max(P.solve_n.scratch_elems, P.solve_t.scratch_elems); // the private slots of the sweeps
+    HIP_OK(hipMalloc((void **)&f.solve_scratch, std::max<size_t>(slots * 8, 16)));
     for (int pass = 0; pass < 2; pass++) {
         const Program &G = pass ? P.solve_t : P.solve_n;
         DevProgram &dp = pass ? f.solve_t : f.solve_n;
         HIP_OK(hipMalloc((void **)&dp.tasks, std::max<size_t>(G.tasks.size() * sizeof(Task), 16)));
         HIP_OK(hipMalloc((void **)&dp.seg, std::max<size_t>(G.seg.size() * sizeof(int64_t), 16)));
+        HIP_OK(hipMalloc((void **)&dp.aux, std::max<size_t>(G.aux.size() * sizeof(int64_t), 16)));
+        if (!G.aux.empty()) HIP_OK(hipMemcpy(dp.aux, G.aux.data(), G.aux.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         dp.n_tasks = G.tasks.size(); dp.n_seg = G.seg.size();
         if (!G.tasks.empty()) HIP_OK(hipMemcpy(dp.tasks, G.tasks.data(), G.tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
         if (!G.seg.empty()) HIP_OK(hipMemcpy(dp.seg, G.seg.data(), G.seg.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -991,13 +1013,16 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
     HM_CHECK(ldb >= f->n && mu >= 0, "factor solve: bad leading dimension");
     if (f->n == 0 || mu == 0) return;
     HIP_OK(hipSetDevice(f->device));
-    const Ctx c = f->ctx(nullptr, (double *)B_dev, ldb, mu);
+    // (the private slots of a sweep hold SOLVE_SLOT_COLUMNS right-hand sides: more run in chunks)
+    for (int c0 = 0; c0 < mu; c0 += SOLVE_SLOT_COLUMNS) {
+    const Ctx c = f->ctx(f->solve_scratch, (double *)B_dev + (long long)c0 * ldb, ldb, std::min(SOLVE_SLOT_COLUMNS, mu - c0));
     // (the caller's stream as it is: NULL is the legacy default stream, which orders this against the caller's other default-stream work and
     // against every blocking stream -- substituting the operator's own stream here would let a product on ANOTHER handle's stream overtake it)
     run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, (hipStream_t)stream);
+    }
     if (getenv("HTOOL_HLU_PROFILE") && atoi(getenv("HTOOL_HLU_PROFILE")) > 1) { // (every launch was waited for: where the time of a solve goes)
-        static const char *names[T_NTYPES] = {"FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF"};
-        for (int q = 1; q <= 2; q++) {
+        static const char *names[T_NTYPES] = {"FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF", "REDUCE"};
+        for (int q : {1, 2, 7}) {
             fprintf(stderr, "[hlu solve profile] %-12s %9.4f s  %8lld launches  %10lld tasks  longest launch %.6f s\n", names[q], g_prof_seconds[q], g_prof_launches[q], g_prof_items[q], g_prof_longest[q]);
             g_prof_seconds[q] = 0; g_prof_launches[q] = 0; g_prof_items[q] = 0; g_prof_longest[q] = 0;
         }
@@ -1062,6 +1087,8 @@ static DeviceHLU *hlu_factor_impl(const HMatrix &H, int kind, double shift, doub
     prm.cap_factor = 2.5 * std::max(1.0, std::log(prm.eps) / std::log(eb)); // (measured: the ranks of the factors reach 2.5-3 x those of the operator at a tenth of its tolerance)
     if (const char *e = getenv("HTOOL_HLU_CAP_FACTOR")) if (atof(e) > 0) prm.cap_factor = atof(e);
     if (const char *e = getenv("HTOOL_HLU_WINDOW_MB")) if (atof(e) > 0) prm.window_scratch_elems = (int64_t)(atof(e) * 1e6 / 8);
+    if (const char *e = getenv("HTOOL_HLU_SUPER_ROWS")) prm.super_rows = atoi(e); // (diagonal blocks of at most this many rows get explicit inverse factors; 0: none)
+    if (const char *e = getenv("HTOOL_HLU_SOLVE_SLOTS")) prm.solve_slots = atoi(e) != 0; // (0: the leaves of a block step subtract one after the other, as in the first version)
     if (const char *e = getenv("HTOOL_HLU_SPLIT")) { // "min,part,max": how long runs of updates of one leaf are dealt out (hlu.hpp: Params::split_*)
         int a = 0, b = 0, c3 = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c3) == 3 && a >= 1 && b >= 1 && c3 >= 1) { prm.split_min = a; prm.split_part = b; prm.split_max_parts = c3; }
@@ -1103,13 +1130,22 @@ static DeviceHLU *hlu_factor_impl(const HMatrix &H, int kind, double shift, doub
     f->seconds[1] = wall_seconds() - t_unpack;
     const double t_fact = wall_seconds();
     hlu_run_windows(*f, 0, (int)P.factor.size() - 1, D->stream);
+    if (!P.invert.tasks.empty()) { // the explicit inverse factors of the small diagonal blocks: what the sweeps of a solve will multiply with
+        DevBuf it, is;
+        it.alloc(P.invert.tasks.size() * sizeof(Task));
+        is.alloc(std::max<size_t>(P.invert.seg.size(), 1) * sizeof(int64_t));
+        DevProgram dp;
+        upload_program(P.invert, it, is, dp, D->stream);
+        run_program(P.invert, dp, f->ctx(nullptr, nullptr, 0, 0), P.leaves, D->stream);
+        HIP_OK(hipStreamSynchronize(D->stream));
+    }
     f->seconds[2] = wall_seconds() - t_fact;
     if (getenv("HTOOL_HLU_PROFILE") && atoi(getenv("HTOOL_HLU_PROFILE")) > 0) {
         long long cc[8];
         HIP_OK(hipMemcpy(cc, f->counters, sizeof(cc), hipMemcpyDeviceToHost));
         fprintf(stderr, "[hlu profile] truncations %lld: Gram %.3f s, first Cholesky + products %.3f s, second Cholesky %.3f s, transforms %.3f s, application %.3f s (workgroup time, summed)\n", cc[1],
                 (double)((unsigned long long)cc[5] >> 32) * 1e-8, (double)(cc[5] & 0xffffffffll) * 1e-8, (double)((unsigned long long)cc[6] >> 32) * 1e-8, (double)(cc[6] & 0xffffffffll) * 1e-8, (double)cc[7] * 1e-8);
-        static const char *names[T_NTYPES] = {"FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF"};
+        static const char *names[T_NTYPES] = {"FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF", "REDUCE"};
         for (int q = 0; q < T_NTYPES; q++) {
             fprintf(stderr, "[hlu profile] %-12s %9.3f s  %8lld launches  %10lld tasks  longest launch %.4f s\n", names[q], g_prof_seconds[q], g_prof_launches[q], g_prof_items[q], g_prof_longest[q]);
             g_prof_seconds[q] = 0; g_prof_launches[q] = 0; g_prof_items[q] = 0; g_prof_longest[q] = 0;
@@ -1277,6 +1313,16 @@ extern "C" int htool_hlu_debug_execute(const htool_hlu_plan *plan_, int first, i
         if (first >= 0) {
             HM_CHECK(last < (int)P->factor.size() && first <= last, "htool_hlu_debug_execute: no such window");
             hlu_run_windows(f, first, last, st, scratch);
+        } else if (first == -3) {
+            if (!P->invert.tasks.empty()) {
+                DevBuf it, is;
+                it.alloc(P->invert.tasks.size() * sizeof(Task));
+                is.alloc(std::max<size_t>(P->invert.seg.size(), 1) * sizeof(int64_t));
+                DevProgram dp;
+                upload_program(P->invert, it, is, dp, st);
+                run_program(P->invert, dp, f.ctx(nullptr, nullptr, 0, 0), P->leaves, st);
+                HIP_OK(hipStreamSynchronize(st));
+            }
         } else {
             HM_CHECK(rhs != nullptr && ld_rhs >= P->n, "htool_hlu_debug_execute: a solve needs right-hand sides");
             hlu_upload_solves(f);

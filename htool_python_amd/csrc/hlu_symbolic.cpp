@@ -507,9 +507,146 @@ struct Emitter {
         return c;
     }
 
+    // ---- diagonal blocks with explicit inverse factors (hlu.hpp: Super) ----
+    std::vector<int> super_of;        // per cluster node: its record, or -1
+    std::vector<Track> trS;
+    bool use_super = false;           // (solve programs only: the sweep inside such a block is one dense product)
+    void choose_supers(int t, int64_t &de) {
+        if (T.size[t] == 0) return;
+        const int d = diag_bnode[t];
+        if (d < 0 || bn[d].leaf >= 0) return; // (a cluster leaf has its inverse factors already)
+        if (T.size[t] <= P.params.super_rows) {
+            Super S;
+            S.node = t; S.m = T.size[t];
+            S.linv = de; de += (int64_t)S.m * S.m;
+            S.uinv = S.linv;
+            if (!P.params.symmetric) { S.uinv = de; de += (int64_t)S.m * S.m; }
+            super_of[t] = (int)P.supers.size();
+            P.supers.push_back(S);
+            return;
+        }
+        for (int a = 0; a < T.n_child[t]; a++) choose_supers(T.first_child[t] + a, de);
+    }
+    void apply_super(int t, int which, bool trans, const Thin &X, int kref, int kconst) {
+        const Super &S = P.supers[(size_t)super_of[t]];
+        if (X.space == SP_RHS && P.params.solve_slots && aux_out != nullptr) {
+            // a dense product of ~1000 x 1000 by ONE workgroup is 0.4 ms of streaming: the rows are dealt out 64 at a time into a private slot
+            // (one launch, all pieces side by side), then copied back by a REDUCE task that assigns instead of subtracting
+            const int64_t slot = solve_scratch_used;
+            solve_scratch_used += (((int64_t)S.m * SOLVE_SLOT_COLUMNS) + 1) & ~(int64_t)1;
+            const int64_t mref = which ? S.uinv : S.linv;
+            int lmax = 0;
+            const int dep0 = std::max(trS[(size_t)super_of[t]].dep_read_all(), X.tr->dep_read(cell0[t], cell1[t]));
+            for (int r0 = 0; r0 < S.m; r0 += 64) {
+                const int mc = std::min(64, S.m - r0);
+                Task tk = blank(T_APPLY_DENSE);
+                tk.flags = trans ? F_TRANS : 0;
+                tk.kref = kref; tk.kconst = kconst;
+                tk.m = mc; tk.n = S.m;
+                tk.a = make_ref(SP_DIAG, mref + (trans ? (int64_t)r0 * S.m : (int64_t)r0)); tk.a_ld = S.m;
+                tk.x = ref(X, T.offset[t]); tk.x_ld = X.ld;
+                tk.y = make_ref(SP_SCRATCH, slot + r0); tk.y_ld = S.m;
+                lmax = std::max(lmax, emit(tk, dep0));
+            }
+            trS[(size_t)super_of[t]].note_read_all(lmax);
+            X.tr->note_read(cell0[t], cell1[t], lmax);
+            Task rd = blank(T_REDUCE); // (no F_SUB: Y = the contribution)
+            rd.kref = kref; rd.kconst = 1;
+            rd.m = S.m;
+            rd.a = (int64_t)aux_out->size() / 2;
+            aux_out->push_back(make_ref(SP_SCRATCH, slot)); aux_out->push_back(S.m);
+            rd.y = ref(X, T.offset[t]); rd.y_ld = X.ld;
+            const int lev = emit(rd, std::max(lmax, X.tr->dep_write(cell0[t], cell1[t])));
+            X.tr->note_write(cell0[t], cell1[t], lev);
+            return;
+        }
+        Task tk = blank(T_APPLY_DENSE);
+        tk.flags = F_INPLACE | (trans ? F_TRANS : 0);
+        tk.kref = kref; tk.kconst = kconst;
+        tk.m = tk.n = S.m;
+        tk.a = make_ref(SP_DIAG, which ? S.uinv : S.linv); tk.a_ld = S.m;
+        tk.x = tk.y = ref(X, T.offset[t]); tk.x_ld = tk.y_ld = X.ld;
+        const int dep = std::max(trS[(size_t)super_of[t]].dep_read_all(), X.tr->dep_write(cell0[t], cell1[t]));
+        const int lev = emit(tk, dep);
+        trS[(size_t)super_of[t]].note_read_all(lev);
+        X.tr->note_write(cell0[t], cell1[t], lev);
+    }
+    void plan_inverses() { // identity, then the sweep of the block itself on all its columns at once
+        for (size_t q = 0; q < P.supers.size(); q++) {
+            const Super &S = P.supers[q];
+            const int t = S.node;
+            for (int which = 0; which < (P.params.symmetric ? 1 : 2); which++) {
+                temp_tracks.emplace_back();
+                temp_tracks.back().init(cell0[t], cell1[t] - cell0[t]);
+                Thin X;
+                X.base = which ? S.uinv : S.linv; X.ld = S.m; X.pos0 = T.offset[t]; X.space = SP_DIAG; X.tr = &temp_tracks.back();
+                Task f = blank(T_FILL);
+                f.flags = F_IDENT;
+                f.m = S.m; f.kref = -1; f.kconst = S.m;
+                f.y = ref(X, T.offset[t]); f.y_ld = S.m;
+                const int lev = emit(f, X.tr->dep_write(cell0[t], cell1[t]));
+                X.tr->note_write(cell0[t], cell1[t], lev);
+                if (which == 0) thin_solve_l(t, X, -1, S.m);
+                else thin_solve_u(t, X, -1, S.m);
+            }
+        }
+    }
+    // ---- (solve programs) one step of a sweep: X[rows of the output side of block b] -= op(block b restricted to (t, s)) X[rows of its input side] ----
+    std::vector<int> cellpos, cellsize;     // first position / rows of every cluster-leaf cell
+    int64_t solve_scratch_used = 0;
+    std::vector<int64_t> *aux_out = nullptr;
+    struct Contrib { int64_t ref; int ld; int level; };
+    void block_step(int b, int t, int s, bool trans, const Thin &X, int kref, int kconst) {
+        if (planning_factor || !use_super || X.space != SP_RHS || !P.params.solve_slots || aux_out == nullptr) {
+            for_leaves(b, t, s, [&](int l, int it, int is) { apply_leaf(l, it, is, trans, X, X, kref, kconst, true, true); });
+            return;
+        }
+        const int outn = trans ? s : t, c0 = cell0[outn], c1 = cell1[outn];
+        std::vector<std::vector<Contrib>> per_cell((size_t)(c1 - c0));
+        for_leaves(b, t, s, [&](int l, int it, int is) {
+            const Leaf &L = P.leaves[l];
+            const int in = trans ? it : is, out = trans ? is : it;
+            const int64_t slot = solve_scratch_used;
+            solve_scratch_used += (((int64_t)T.size[out] * SOLVE_SLOT_COLUMNS) + 1) & ~(int64_t)1;
+            Task tk = blank(L.kind == 1 ? T_APPLY_LR : T_APPLY_DENSE);
+            tk.leaf = l;
+            tk.flags = trans ? F_TRANS : 0; // (Y = op(leaf) X: no accumulation, the slot is this task's own)
+            tk.kref = kref; tk.kconst = kconst;
+            tk.m = T.size[out];
+            tk.n = T.size[in];
+            if (L.kind == 1) {
+                const int64_t urow = L.u + (T.offset[it] - L.t_off), vrow = L.v + (T.offset[is] - L.s_off);
+                tk.a = make_ref(SP_FACTOR, trans ? vrow : urow); tk.a_ld = trans ? L.n : L.m;
+                tk.b = make_ref(SP_FACTOR, trans ? urow : vrow); tk.b_ld = trans ? L.m : L.n;
+            } else { tk.a = make_ref(SP_FACTOR, L.u); tk.a_ld = L.m; }
+            tk.x = ref(X, T.offset[in]); tk.x_ld = X.ld;
+            tk.y = make_ref(SP_SCRATCH, slot); tk.y_ld = T.size[out];
+            const int dep = std::max(dep_leaf_read(l), X.tr->dep_read(cell0[in], cell1[in]));
+            const int lev = emit(tk, dep);
+            note_leaf_read(l, lev);
+            X.tr->note_read(cell0[in], cell1[in], lev);
+            for (int c = cell0[out]; c < cell1[out]; c++)
+                per_cell[(size_t)(c - c0)].push_back({make_ref(SP_SCRATCH, slot + (cellpos[c] - T.offset[out])), T.size[out], lev});
+        });
+        for (int c = c0; c < c1; c++) {
+            const std::vector<Contrib> &v = per_cell[(size_t)(c - c0)];
+            if (v.empty()) continue;
+            Task tk = blank(T_REDUCE);
+            tk.flags = F_SUB;
+            tk.kref = kref; tk.kconst = (int32_t)v.size();
+            tk.m = cellsize[c];
+            tk.a = (int64_t)aux_out->size() / 2;
+            tk.y = make_ref(X.space, X.base + (cellpos[c] - X.pos0)); tk.y_ld = X.ld;
+            int dep = X.tr->dep_write(c, c + 1);
+            for (const Contrib &q : v) { aux_out->push_back(q.ref); aux_out->push_back(q.ld); dep = std::max(dep, q.level); }
+            const int lev = emit(tk, dep);
+            X.tr->note_write(c, c + 1, lev);
+        }
+    }
     // X[rows of t] <- L(t,t)^-1 X[rows of t]   (forward substitution through the leaves of L)
     void thin_solve_l(int t, const Thin &X, int kref, int kconst) {
         if (T.size[t] == 0) return;
+        if (use_super && super_of[t] >= 0) { apply_super(t, 0, false, X, kref, kconst); return; }
         if (bn[diag_bnode[t]].leaf >= 0) { apply_diag(t, 0, false, X, kref, kconst); return; }
         const int nc = T.n_child[t], f = T.first_child[t];
         for (int i = 0; i < nc; i++) {
@@ -517,13 +654,14 @@ struct Emitter {
             thin_solve_l(f + i, X, kref, kconst);
             for (int j = i + 1; j < nc; j++) {
                 if (T.size[f + j] == 0) continue;
-                for_leaves(block_of(f + j, f + i), f + j, f + i, [&](int l, int it, int is) { apply_leaf(l, it, is, false, X, X, kref, kconst, true, true); });
+                block_step(block_of(f + j, f + i), f + j, f + i, false, X, kref, kconst);
             }
         }
     }
     // X[rows of s] <- U(s,s)^-T X[rows of s]   (forward substitution with the transposed upper factor)
     void thin_solve_ut(int s, const Thin &X, int kref, int kconst) {
         if (T.size[s] == 0) return;
+        if (use_super && super_of[s] >= 0) { apply_super(s, P.params.symmetric ? 0 : 1, true, X, kref, kconst); return; }
         if (bn[diag_bnode[s]].leaf >= 0) { apply_diag(s, 1, true, X, kref, kconst); return; }
         const int nc = T.n_child[s], f = T.first_child[s];
         for (int i = 0; i < nc; i++) {
@@ -531,13 +669,14 @@ struct Emitter {
             thin_solve_ut(f + i, X, kref, kconst);
             for (int j = i + 1; j < nc; j++) {
                 if (T.size[f + j] == 0) continue;
-                for_leaves(block_of(f + i, f + j), f + i, f + j, [&](int l, int it, int is) { apply_leaf(l, it, is, true, X, X, kref, kconst, true, true); });
+                block_step(block_of(f + i, f + j), f + i, f + j, true, X, kref, kconst);
             }
         }
     }
     // X[rows of t] <- U(t,t)^-1 X[rows of t]   (backward substitution)
     void thin_solve_u(int t, const Thin &X, int kref, int kconst) {
         if (T.size[t] == 0) return;
+        if (use_super && super_of[t] >= 0) { apply_super(t, P.params.symmetric ? 0 : 1, false, X, kref, kconst); return; }
         if (bn[diag_bnode[t]].leaf >= 0) { apply_diag(t, 1, false, X, kref, kconst); return; }
         const int nc = T.n_child[t], f = T.first_child[t];
         for (int i = nc - 1; i >= 0; i--) {
@@ -545,13 +684,14 @@ struct Emitter {
             thin_solve_u(f + i, X, kref, kconst);
             for (int j = i - 1; j >= 0; j--) {
                 if (T.size[f + j] == 0) continue;
-                for_leaves(block_of(f + j, f + i), f + j, f + i, [&](int l, int it, int is) { apply_leaf(l, it, is, false, X, X, kref, kconst, true, true); });
+                block_step(block_of(f + j, f + i), f + j, f + i, false, X, kref, kconst);
             }
         }
     }
     // X[rows of t] <- L(t,t)^-T X[rows of t]   (backward substitution with the transposed lower factor)
     void thin_solve_lt(int t, const Thin &X, int kref, int kconst) {
         if (T.size[t] == 0) return;
+        if (use_super && super_of[t] >= 0) { apply_super(t, 0, true, X, kref, kconst); return; }
         if (bn[diag_bnode[t]].leaf >= 0) { apply_diag(t, 0, true, X, kref, kconst); return; }
         const int nc = T.n_child[t], f = T.first_child[t];
         for (int i = nc - 1; i >= 0; i--) {
@@ -559,7 +699,7 @@ struct Emitter {
             thin_solve_lt(f + i, X, kref, kconst);
             for (int j = i - 1; j >= 0; j--) {
                 if (T.size[f + j] == 0) continue;
-                for_leaves(block_of(f + i, f + j), f + i, f + j, [&](int l, int it, int is) { apply_leaf(l, it, is, true, X, X, kref, kconst, true, true); });
+                block_step(block_of(f + i, f + j), f + i, f + j, true, X, kref, kconst);
             }
         }
     }
@@ -829,7 +969,7 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
         std::vector<int> leaves;
         for (int v = 0; v < nn; v++) if (T.is_leaf(v) && T.size[v] > 0) leaves.push_back(v);
         std::sort(leaves.begin(), leaves.end(), [&](int x, int y) { return T.offset[x] < T.offset[y]; });
-        for (size_t c = 0; c < leaves.size(); c++) { E.cell0[leaves[c]] = (int)c; E.cell1[leaves[c]] = (int)c + 1; }
+        for (size_t c = 0; c < leaves.size(); c++) { E.cell0[leaves[c]] = (int)c; E.cell1[leaves[c]] = (int)c + 1; E.cellpos.push_back(T.offset[leaves[c]]); E.cellsize.push_back(T.size[leaves[c]]); }
         for (int v = nn - 1; v >= 0; v--) { // children have larger ids than their parent
             if (T.is_leaf(v)) continue;
             int lo = INT32_MAX, hi = 0;
@@ -883,7 +1023,6 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
         HM_CHECK(fresh, "hierarchical LU: a block appears twice among the leaves");
     }
     P.factor_elems = fe;
-    P.diag_elems = de;
     P.n_real_leaves = (int64_t)in.size();
     E.next_slot = (int64_t)in.size();
     E.diag_bnode.assign(nn, -1);
@@ -893,6 +1032,10 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
         for (const BNode &b : E.bn) used += b.leaf >= 0;
         HM_CHECK(used == (int64_t)in.size(), "hierarchical LU: leaves outside the block tree of the cluster tree (an operator built with other splitting rules)");
     }
+    E.super_of.assign(nn, -1);
+    if (prm.super_rows > 0) E.choose_supers(root, de);
+    E.trS.resize(P.supers.size());
+    P.diag_elems = de;
     E.trU.resize(in.size());
     E.trV.resize(in.size());
     E.trD.resize(P.diags.size());
@@ -910,8 +1053,22 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
     E.close_window();
     P.n_slots = E.next_slot;
     P.leaves.resize((size_t)E.next_slot, Leaf{0, 0, 0, 0, 0, 0, 0, 0, -1, 0}); // (one record per rank slot: the stage blocks have theirs, the others are unused)
-    // the two solves: fresh dependency state, the factors are read only
+    // the inverse factors of the small diagonal blocks, then the two solves: fresh dependency state, the factors are read only
     E.planning_factor = false;
+    if (!P.supers.empty()) {
+        for (Track &t : E.trU) t = Track();
+        for (Track &t : E.trV) t = Track();
+        for (Track &t : E.trD) t = Track();
+        E.window_base = 1; E.max_level = 0; E.scratch_used = 0;
+        E.temp_tracks.clear();
+        int64_t keep[T_NTYPES];
+        for (int q = 0; q < T_NTYPES; q++) keep[q] = P.counts[q];
+        E.plan_inverses();
+        for (int q = 0; q < T_NTYPES; q++) P.counts[q] = keep[q];
+        E.finish_program(E.cur, P.invert);
+        E.temp_tracks.clear();
+    }
+    E.use_super = true;
     for (int pass = 0; pass < 2; pass++) {
         for (Track &t : E.trU) t = Track();
         for (Track &t : E.trV) t = Track();
@@ -923,11 +1080,15 @@ Plan *make_plan(const ClusterTree &T, const std::vector<LeafIn> &in, const Param
         X.base = 0; X.ld = -1; X.pos0 = P.pos0; X.space = SP_RHS; X.tr = &rhs;
         int64_t keep[T_NTYPES];
         for (int q = 0; q < T_NTYPES; q++) keep[q] = P.counts[q];
+        Program &SG = pass == 0 ? P.solve_n : P.solve_t;
+        E.aux_out = &SG.aux;
+        E.solve_scratch_used = 0;
         if (prm.symmetric) { E.thin_solve_l(root, X, -2, 0); E.thin_solve_lt(root, X, -2, 0); } // A = L L^T: the same sweeps for A and A^T
         else if (pass == 0) { E.thin_solve_l(root, X, -2, 0); E.thin_solve_u(root, X, -2, 0); }
         else { E.thin_solve_ut(root, X, -2, 0); E.thin_solve_lt(root, X, -2, 0); }
         for (int q = 0; q < T_NTYPES; q++) P.counts[q] = keep[q];
-        E.finish_program(E.cur, pass == 0 ? P.solve_n : P.solve_t);
+        E.finish_program(E.cur, SG);
+        SG.scratch_elems = E.solve_scratch_used; // (the private slots of the sweeps: SOLVE_SLOT_COLUMNS right-hand sides at a time)
     }
     P.plan_seconds = wall_seconds() - t0;
     return plan.release();

@@ -910,16 +910,18 @@ PYBIND11_MODULE(Htool, m) {
             })
         .def("program", [](const PyHluPlan &s, int which) { // copies: (tasks as bytes (n, 96), buckets as int64 (n, 5), runs, scratch elements)
                 const void *tasks, *buckets;
-                const int64_t *seg;
-                int64_t nt, nb, ns, scratch;
-                check(htool_hlu_plan_program(s.p, which, &tasks, &nt, &buckets, &nb, &seg, &ns, &scratch));
+                const int64_t *seg, *aux;
+                int64_t nt, nb, ns, scratch, na;
+                check(htool_hlu_plan_program(s.p, which, &tasks, &nt, &buckets, &nb, &seg, &ns, &scratch, &aux, &na));
+                py::array_t<int64_t> ax((py::ssize_t)na);
+                if (na) std::memcpy(ax.mutable_data(), aux, (size_t)na * 8);
                 py::array_t<uint8_t> t({(py::ssize_t)nt, (py::ssize_t)96});
                 std::memcpy(t.mutable_data(), tasks, (size_t)nt * 96);
                 py::array_t<int64_t> b({(py::ssize_t)nb, (py::ssize_t)5});
                 std::memcpy(b.mutable_data(), buckets, (size_t)nb * 40);
                 py::array_t<int64_t> g((py::ssize_t)ns);
                 std::memcpy(g.mutable_data(), seg, (size_t)ns * 8);
-                return py::make_tuple(t, b, g, scratch);
+                return py::make_tuple(t, b, g, scratch, ax);
             }, "which"_a)
         .def("debug_execute", [](const PyHluPlan &s, int first, int last, py::array_t<double> factor, py::array_t<double> diag, py::array_t<int32_t> rank,
                                  py::array_t<double> norm0, py::array_t<double> norm2, py::array_t<int64_t> counters, py::object rhs, long long ld_rhs, int nrhs, py::object scratch) {

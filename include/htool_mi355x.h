@@ -377,8 +377,8 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
  * of a square operator on the cluster tree of `root`, rank < 0 for a dense leaf; the plan is host data only (no device needed).
  * symmetric != 0: the operator is symmetric positive definite and rects5 holds its LOWER triangle only (diagonal leaves included): the plan
  * is the hierarchical Cholesky factorisation A = L L^T.  htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
- * each, struct hm::hlu::Task), launch buckets and target runs of one window of the factorisation (which >= 0) or of the
- * solves (-1: 'N', -2: 'T'); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
+ * each, struct hm::hlu::Task), launch buckets, target runs and (solves) the contribution lists of the REDUCE tasks of one window of the factorisation (which >= 0) or of the
+ * solves (-1: 'N', -2: 'T') or of the program that forms the explicit inverse factors of the small diagonal blocks after the factorisation (-3); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
 /* what htool_hmatrix_lu_factorization / _cholesky_factorization left behind: out17[0] = 0 nothing, 1 dense on the host, 2 dense on
  * the device, 3 hierarchical; for 3, out17[1..16] = unknowns, leaves, tasks, launches, windows, bytes of the factors as they stay resident (tight: their rank in columns), bytes of the arena (64 columns of room per leaf) and scratch while factorising,
  * truncations cut at a leaf's capacity, truncations, appended columns, columns out of dense-leaf products, tasks and launches of one
@@ -390,10 +390,10 @@ int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int
                           int64_t window_scratch_elems, int64_t window_tasks, int symmetric, htool_hlu_plan **out);
 int htool_hlu_plan_info(const htool_hlu_plan *plan, int64_t *out, int n_out);
 int htool_hlu_plan_program(const htool_hlu_plan *plan, int which, const void **tasks, int64_t *n_tasks, const void **buckets, int64_t *n_buckets,
-                           const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems);
+                           const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems, const int64_t **aux, int64_t *n_aux);
 int htool_hlu_plan_tables(const htool_hlu_plan *plan, const void **leaves, const void **diags);
 void htool_hlu_plan_free(htool_hlu_plan *plan);
-/* diagnostic: windows first..last of the plan's factorisation (first >= 0), or one of its solves (first = -1 'N', -2 'T') executed by
+/* diagnostic: windows first..last of the plan's factorisation (first >= 0), or one of its solves (first = -1 'N', -2 'T'), or the inverse factors of the small diagonal blocks (first = -3), executed by
  * the DEVICE kernels on host arrays laid out as the plan says (uploaded, run, downloaded) -- the counterpart of the CPU checker
  * oracle/hlu_exec.cpp, which tests feed the same arrays.  counters: 8 values; scratch (may be NULL): the window's scratch space, in and out. */
 int htool_hlu_debug_execute(const htool_hlu_plan *plan, int first, int last, double *factor, double *diag, int32_t *rank, double *norm0, double *norm2,

@@ -39,7 +39,7 @@ def lib():
         build()
         L = ctypes.CDLL(_LIB_PATH)
         vp, i64, ci, cd, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_uint64
-        L.hluo_run.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, ci, vp, vp, vp, cd, vp, u64]
+        L.hluo_run.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, ci, vp, vp, vp, cd, vp, u64, vp]
         _lib = L
     return _lib
 
@@ -82,6 +82,11 @@ class HostLU:
         if run:
             for w in range(I["windows"]):
                 self.run_window(w, shuffle)
+            self.run_inverses(shuffle)
+
+    def run_inverses(self, shuffle=0):
+        """The explicit inverse factors of the small diagonal blocks (program -3): after the last window, before any solve."""
+        self._run(-3, None, 0, shuffle)
 
     def run_window(self, w, shuffle=0, max_buckets=None):
         self._run(w, None, 0, shuffle, max_buckets)
@@ -96,14 +101,16 @@ class HostLU:
         return self.factor[L["u"]:L["u"] + m * r].reshape(r, m).T @ self.factor[L["v"]:L["v"] + n * r].reshape(r, n)
 
     def _run(self, which, rhs, nrhs, shuffle=0, max_buckets=None):
-        t, b, g, _ = self.plan.program(which)
-        t, b, g = np.ascontiguousarray(t), np.ascontiguousarray(b), np.ascontiguousarray(g)
+        t, b, g, scratch_elems, ax = self.plan.program(which)
+        t, b, g, ax = np.ascontiguousarray(t), np.ascontiguousarray(b), np.ascontiguousarray(g), np.ascontiguousarray(ax)
+        if scratch_elems > len(self.scratch):
+            self.scratch = np.zeros(scratch_elems)  # (a solve program's private slots)
         nb = b.shape[0] if max_buckets is None else min(b.shape[0], max_buckets)
         if which >= 0:
             self.scratch[:] = np.nan  # (a window must not read scratch it has not written)
         lib().hluo_run(_p(t), t.shape[0], _p(b), nb, _p(g), _p(self.leaves), _p(self.diags), _p(self.factor), _p(self.diag), _p(self.scratch),
                        _p(rhs), 0 if rhs is None else self.info["n"], nrhs,
-                       _p(self.rank), _p(self.norm0), _p(self.norm2), self.eps, _p(self.counters), shuffle)
+                       _p(self.rank), _p(self.norm0), _p(self.norm2), self.eps, _p(self.counters), shuffle, _p(ax) if len(ax) else None)
 
     def solve(self, b_cluster, trans="N", shuffle=0):
         """b in CLUSTER numbering, (n,) or (n, q); returns A^-1 b (or A^-T b)."""
@@ -113,7 +120,10 @@ class HostLU:
         X = np.asfortranarray(B.copy())
         flat = X.ravel(order="F")  # (a view of X: column-major, ld = n)
         assert np.shares_memory(flat, X)
-        self._run(-1 if trans == "N" else -2, flat, X.shape[1], shuffle)
+        n = X.shape[0]
+        for c0 in range(0, X.shape[1], 8):  # (the private slots of a sweep hold 8 right-hand sides: csrc/hlu.hpp SOLVE_SLOT_COLUMNS)
+            w = min(8, X.shape[1] - c0)
+            self._run(-1 if trans == "N" else -2, flat[c0 * n:(c0 + w) * n], w, shuffle)
         return X[:, 0] if np.ndim(b_cluster) == 1 else X
 
     def ranks(self):

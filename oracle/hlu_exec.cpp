@@ -17,8 +17,8 @@
 
 namespace {
 
-enum { T_FILL = 0, T_APPLY_DENSE = 1, T_APPLY_LR = 2, T_ADDLR = 3, T_FINAL = 4, T_DDPROD = 5, T_GETRF = 6 };
-enum { F_TRANS = 1, F_INPLACE = 2, F_ACCUM = 4, F_SUB = 8, F_XT = 16, F_YT = 32, F_SYM = 64 };
+enum { T_FILL = 0, T_APPLY_DENSE = 1, T_APPLY_LR = 2, T_ADDLR = 3, T_FINAL = 4, T_DDPROD = 5, T_GETRF = 6, T_REDUCE = 7 };
+enum { F_TRANS = 1, F_INPLACE = 2, F_ACCUM = 4, F_SUB = 8, F_XT = 16, F_YT = 32, F_SYM = 64, F_IDENT = 128 };
 struct Task {
     int32_t type, flags, level, leaf, kref, kconst, m, n, r0, c0, a_ld, b_ld, x_ld, y_ld;
     int64_t a, b, x, y, w;
@@ -38,6 +38,7 @@ struct State {
     double *norm0, *norm2;
     double eps;
     int64_t *counters; // [0] forced truncations, [1] recompressions, [2] appended columns, [3] ddprod columns
+    const int64_t *aux = nullptr; // REDUCE tasks of a solve program: (reference, leading dimension) of every contribution
 };
 
 inline double *at(const State &S, int64_t ref) { return S.space[(int)(ref >> 60)] + (ref & (((int64_t)1 << 60) - 1)); }
@@ -166,11 +167,23 @@ void recompress(State &S, int l) {
 
 void run_task(State &S, const Task &t) {
     switch (t.type) {
+    case T_REDUCE: { // Y[rows of a cluster leaf] -= the private contributions, summed in the order of the list
+        const int q = cols_of(S, t);
+        double *y = at(S, t.y);
+        const int64_t yl = ld_of(S, t.y, t.y_ld);
+        for (int c = 0; c < q; c++)
+            for (int i = 0; i < t.m; i++) {
+                double s = 0;
+                for (int k = 0; k < t.kconst; k++) s += at(S, S.aux[2 * (t.a + k)])[i + c * S.aux[2 * (t.a + k) + 1]];
+                if (t.flags & F_SUB) y[i + c * yl] -= s; else y[i + c * yl] = s; // (without F_SUB: a copy back from a slot)
+            }
+        break;
+    }
     case T_FILL: {
         const int q = cols_of(S, t);
         double *y = at(S, t.y);
         const int64_t ld = ld_of(S, t.y, t.y_ld);
-        for (int c = 0; c < q; c++) for (int i = 0; i < t.m; i++) y[i + c * ld] = 0.0;
+        for (int c = 0; c < q; c++) for (int i = 0; i < t.m; i++) y[i + c * ld] = ((t.flags & F_IDENT) && i == c) ? 1.0 : 0.0;
         break;
     }
     case T_APPLY_DENSE: {
@@ -336,12 +349,13 @@ extern "C" {
 // items of a bucket (tasks, or runs of one target) are executed in a pseudo-random order -- the result must not change.
 int hluo_run(const void *tasks_, int64_t n_tasks, const void *buckets_, int64_t n_buckets, const int64_t *seg, const void *leaves, const void *diags,
              double *factor, double *diag, double *scratch, double *rhs, int64_t ld_rhs, int nrhs, int32_t *rank, double *norm0, double *norm2, double eps,
-             int64_t *counters, uint64_t shuffle) {
+             int64_t *counters, uint64_t shuffle, const int64_t *aux) {
     const Task *tasks = (const Task *)tasks_;
     const Bucket *buckets = (const Bucket *)buckets_;
     State S;
     S.leaves = (const Leaf *)leaves; S.diags = (const Diag *)diags;
     S.space[0] = factor; S.space[1] = diag; S.space[2] = scratch; S.space[3] = rhs;
+    S.aux = aux;
     S.ld_rhs = ld_rhs; S.nrhs = nrhs; S.rank = rank; S.norm0 = norm0; S.norm2 = norm2; S.eps = eps; S.counters = counters;
     uint64_t rng = shuffle * 0x9E3779B97F4A7C15ull + 12345;
     auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };

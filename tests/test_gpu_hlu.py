@@ -72,6 +72,7 @@ def test_device_factorisation_solves_the_system(n, leaf, eta, sym):
     leaf_data = lambda i: H.leaf_data(int(ids[i]))  # noqa: E731
     st = ohlu.HostLU(plan, leaf_data, eps_lu, run=False)
     plan.debug_execute(0, st.info["windows"] - 1, st.factor, st.diag, st.rank, st.norm0, st.norm2, st.counters)
+    plan.debug_execute(-3, 0, st.factor, st.diag, st.rank, st.norm0, st.norm2, st.counters)   # the explicit inverse factors of the small diagonal blocks
     assert st.counters[0] <= 0.02 * st.counters[1] and st.counters[4] == 0   # (truncations cut at a leaf's capacity: rare)
     A = H.to_dense()
     x_ref = np.ones(n)
@@ -87,6 +88,7 @@ def test_device_factorisation_solves_the_system(n, leaf, eta, sym):
     # bitwise reproducible: the same plan on the same data gives the same factors
     st2 = ohlu.HostLU(plan, leaf_data, eps_lu, run=False)
     plan.debug_execute(0, st2.info["windows"] - 1, st2.factor, st2.diag, st2.rank, st2.norm0, st2.norm2, st2.counters)
+    plan.debug_execute(-3, 0, st2.factor, st2.diag, st2.rank, st2.norm0, st2.norm2, st2.counters)
     assert np.array_equal(st.diag, st2.diag) and np.array_equal(st.ranks(), st2.ranks())
     assert np.array_equal(device_solve(plan, st2, B), X)
 

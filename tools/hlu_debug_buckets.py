@@ -19,7 +19,7 @@ plan = Htool.HLUPlan(cl, H.leaves, eps_lu, window_tasks=wt, cap_factor=2 * np.lo
 host = ohlu.HostLU(plan, H.leaf_data, eps_lu, run=False)
 for w in range(win):
     host.run_window(w)
-t, b, g, _ = plan.program(win)
+t, b, g, _, _aux = plan.program(win)
 T = np.ascontiguousarray(t).view(ohlu.TASK).ravel()
 B = np.ascontiguousarray(b)
 names = ["FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF"]

@@ -32,7 +32,7 @@ for w in range(host.info["windows"]):
     print("window %d: worst leaf %d err %.2e kind %d ranks cpu %d gpu %d; slots differ: %d" % (w, i, errs[i], host.leaves["kind"][i], host.rank[i], dev.rank[i],
                                                                                               int((host.rank != dev.rank).sum())))
     if errs[i] > 1e-3:
-        t, b, g, _ = plan.program(w)
+        t, b, g, _, _aux = plan.program(w)
         T = np.ascontiguousarray(t).view(ohlu.TASK).ravel()
         print("leaf", host.leaves[i], "rank before", rank_before[i])
         bad = np.where(errs > 1e-3)[0]
