@@ -19,8 +19,10 @@
 //                           cross approximation with full pivoting on the explicit residual, handed on as X' Z'^T
 //   hlu_getrf_[lds_]kernel  LU with partial pivoting of a diagonal leaf + the explicit inverses (P^T L)^-1 and U^-1, with
 //                           which every triangular solve against a diagonal leaf is a product (leaves of at most 128 rows: in LDS)
-// lu_solve replays the plan's solve program (forward and backward sweep over the leaves) on the caller's block of
-// right-hand sides.
+//   hlu_reduce_kernel       (solves) the private contributions of the leaves of a block step summed per cluster leaf, in plan order
+// After the factorisation the plan's `invert` program forms explicit inverse factors of the diagonal blocks of up to 1024 rows
+// (the block's own sweep on the identity), and the leaves move to a tight arena.  lu_solve replays the plan's solve program
+// (forward and backward sweep) on the caller's block of right-hand sides, eight columns at a time.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
