@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 
 #include "capi_internal.hpp"
@@ -791,13 +792,13 @@ struct DevProgram {
 };
 
 void attributes_once() {
-    static bool done = false;
-    if (done) return;
+    static std::once_flag flag;
+    std::call_once(flag, [] {
     HIP_OK(hipFuncSetAttribute((const void *)hlu_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)update_lds_bytes(64)));
     HIP_OK(hipFuncSetAttribute((const void *)hlu_apply_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HLU_MAX_DIM * QC * (int)sizeof(double)));
     HIP_OK(hipFuncSetAttribute((const void *)hlu_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HLU_MAX_DIM * QC * (int)sizeof(double)));
     HIP_OK(hipFuncSetAttribute((const void *)hlu_getrf_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 18 * 1024 * (int)sizeof(double)));
-    done = true;
+    });
 }
 
 // HTOOL_HLU_PROFILE=1: every launch is waited for and its time added up per task kind (printed by device_hlu_factor)
@@ -902,10 +903,13 @@ struct DeviceHLU {
     long long *counters = nullptr;
     DevProgram solve_n, solve_t;
     double *solve_scratch = nullptr;
+    hipEvent_t last_solve = nullptr;   // the solves of one factorisation share the slots of the sweeps: each waits for the one before, whatever their streams
+    mutable std::mutex solve_mu;
     int64_t stats[16] = {0};
     double seconds[4] = {0, 0, 0, 0}; // plan, unpack, factorisation, total
     ~DeviceHLU() {
         (void)hipSetDevice(device);
+        if (last_solve) (void)hipEventDestroy(last_solve);
         for (void *p : {(void *)factor, (void *)diag, (void *)leaves, (void *)diags, (void *)rank, (void *)norm0, (void *)norm2, (void *)counters, (void *)solve_n.tasks, (void *)solve_n.seg, (void *)solve_n.aux,
                         (void *)solve_t.tasks, (void *)solve_t.seg, (void *)solve_t.aux, (void *)solve_scratch})
             if (p) (void)hipFree(p);
@@ -993,6 +997,7 @@ void hlu_upload_solves(DeviceHLU &f) {
     const Plan &P = *f.plan;
     const size_t slots = (size_t)std::max(P.solve_n.scratch_elems, P.solve_t.scratch_elems); // the private slots of the sweeps
     HIP_OK(hipMalloc((void **)&f.solve_scratch, std::max<size_t>(slots * 8, 16)));
+    HIP_OK(hipEventCreateWithFlags(&f.last_solve, hipEventDisableTiming));
     for (int pass = 0; pass < 2; pass++) {
         const Program &G = pass ? P.solve_t : P.solve_n;
         DevProgram &dp = pass ? f.solve_t : f.solve_n;
@@ -1015,6 +1020,8 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
     HM_CHECK(ldb >= f->n && mu >= 0, "factor solve: bad leading dimension");
     if (f->n == 0 || mu == 0) return;
     HIP_OK(hipSetDevice(f->device));
+    std::lock_guard<std::mutex> lock(f->solve_mu);
+    if (f->last_solve) HIP_OK(hipStreamWaitEvent((hipStream_t)stream, f->last_solve, 0));
     // (the private slots of a sweep hold SOLVE_SLOT_COLUMNS right-hand sides: more run in chunks)
     for (int c0 = 0; c0 < mu; c0 += SOLVE_SLOT_COLUMNS) {
     const Ctx c = f->ctx(f->solve_scratch, (double *)B_dev + (long long)c0 * ldb, ldb, std::min(SOLVE_SLOT_COLUMNS, mu - c0));
@@ -1022,6 +1029,7 @@ void device_hlu_solve(const DeviceHLU *f, char trans, void *B_dev, long long ldb
     // against every blocking stream -- substituting the operator's own stream here would let a product on ANOTHER handle's stream overtake it)
     run_program(trans == 'N' ? f->plan->solve_n : f->plan->solve_t, trans == 'N' ? f->solve_n : f->solve_t, c, f->plan->leaves, (hipStream_t)stream);
     }
+    if (f->last_solve) HIP_OK(hipEventRecord(f->last_solve, (hipStream_t)stream));
     if (getenv("HTOOL_HLU_PROFILE") && atoi(getenv("HTOOL_HLU_PROFILE")) > 1) { // (every launch was waited for: where the time of a solve goes)
         static const char *names[T_NTYPES] = {"FILL", "APPLY_DENSE", "APPLY_LR", "ADDLR", "FINAL", "DDPROD", "GETRF", "REDUCE"};
         for (int q : {1, 2, 7}) {
