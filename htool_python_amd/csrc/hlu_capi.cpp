@@ -34,7 +34,7 @@ std::vector<LeafIn> leaves_from_rects(const ClusterTree &T, int64_t n, const int
 extern "C" {
 
 int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int32_t *rects5, double epsilon, int cap_min, int cap_max, double cap_factor,
-                          int64_t window_scratch_elems, int64_t window_tasks, int symmetric, htool_hlu_plan **out) {
+                          int64_t window_scratch_elems, int64_t window_tasks, int symmetric, int super_rows, int solve_slots, htool_hlu_plan **out) {
     API_BEGIN
     HM_CHECK(root && rects5 && out, "htool_hlu_plan_create: null argument");
     const ClusterHandle *h = reinterpret_cast<const ClusterHandle *>(root);
@@ -46,6 +46,8 @@ int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int
     if (window_scratch_elems > 0) P.window_scratch_elems = window_scratch_elems;
     if (window_tasks > 0) P.window_tasks = window_tasks;
     P.symmetric = symmetric != 0;
+    if (super_rows >= 0) P.super_rows = super_rows;
+    if (solve_slots >= 0) P.solve_slots = solve_slots != 0;
     std::vector<hlu::LeafIn> in = hlu::leaves_from_rects(*h->tree, n_leaves, rects5);
     htool_hlu_plan *p = new htool_hlu_plan;
     try { p->plan = hlu::make_plan(*h->tree, in, P, h->node); } catch (...) { delete p; throw; }

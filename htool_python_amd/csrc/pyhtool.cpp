@@ -893,16 +893,16 @@ PYBIND11_MODULE(Htool, m) {
     };
     py::class_<PyHluPlan, std::shared_ptr<PyHluPlan>>(m, "HLUPlan")
         .def(py::init([](const PyCluster &c, py::array_t<int32_t, py::array::c_style | py::array::forcecast> rects5, double epsilon, int cap_min, int cap_max,
-                         long long window_scratch_elems, long long window_tasks, double cap_factor, bool symmetric) {
+                         long long window_scratch_elems, long long window_tasks, double cap_factor, bool symmetric, int super_rows, int solve_slots) {
                  if (rects5.ndim() != 2 || rects5.shape(1) != 5) throw std::runtime_error("HLUPlan: rects must be (n_leaves, 5) int32: t_off, m, s_off, n, rank");
                  auto pl = std::make_shared<PyHluPlan>();
                  pl->owner = c.owner;
                  {
                      py::gil_scoped_release nogil;
-                     check(htool_hlu_plan_create(c.node, rects5.shape(0), rects5.data(), epsilon, cap_min, cap_max, cap_factor, window_scratch_elems, window_tasks, symmetric ? 1 : 0, &pl->p));
+                     check(htool_hlu_plan_create(c.node, rects5.shape(0), rects5.data(), epsilon, cap_min, cap_max, cap_factor, window_scratch_elems, window_tasks, symmetric ? 1 : 0, super_rows, solve_slots, &pl->p));
                  }
                  return pl;
-             }), "cluster"_a, "rects"_a, "epsilon"_a = 1e-3, "cap_min"_a = 0, "cap_max"_a = 0, "window_scratch_elems"_a = 0, "window_tasks"_a = 0, "cap_factor"_a = 0.0, "symmetric"_a = false)
+             }), "cluster"_a, "rects"_a, "epsilon"_a = 1e-3, "cap_min"_a = 0, "cap_max"_a = 0, "window_scratch_elems"_a = 0, "window_tasks"_a = 0, "cap_factor"_a = 0.0, "symmetric"_a = false, "super_rows"_a = -1, "solve_slots"_a = -1)
         .def("info", [](const PyHluPlan &s) {
                 py::array_t<int64_t> out(23);
                 check(htool_hlu_plan_info(s.p, out.mutable_data(), 23));

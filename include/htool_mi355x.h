@@ -376,7 +376,8 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
  * (csrc/hlu_symbolic.cpp, csrc/hlu.hpp).  The entries below expose that PLAN for tests: rects5 = (t_off, m, s_off, n, rank) per leaf
  * of a square operator on the cluster tree of `root`, rank < 0 for a dense leaf; the plan is host data only (no device needed).
  * symmetric != 0: the operator is symmetric positive definite and rects5 holds its LOWER triangle only (diagonal leaves included): the plan
- * is the hierarchical Cholesky factorisation A = L L^T.  htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
+ * is the hierarchical Cholesky factorisation A = L L^T.  super_rows / solve_slots (-1: the defaults, 1024 / on): how the solve programs are shortened -- explicit
+ * inverse factors for diagonal blocks of at most super_rows rows, private slots + REDUCE tasks for the leaves of a block step (csrc/hlu.hpp).  htool_hlu_plan_info: see csrc/hlu_capi.cpp for the 23 values; htool_hlu_plan_program: the sorted task records (96 bytes
  * each, struct hm::hlu::Task), launch buckets, target runs and (solves) the contribution lists of the REDUCE tasks of one window of the factorisation (which >= 0) or of the
  * solves (-1: 'N', -2: 'T') or of the program that forms the explicit inverse factors of the small diagonal blocks after the factorisation (-3); htool_hlu_plan_tables: leaf and diagonal-leaf records. */
 /* what htool_hmatrix_lu_factorization / _cholesky_factorization left behind: out17[0] = 0 nothing, 1 dense on the host, 2 dense on
@@ -387,7 +388,7 @@ int htool_krylov_finish_step(void *W_dev, int64_t ldw, int n, int mu, int is_com
 int htool_hmatrix_factorization_info(const htool_hmatrix *h, int64_t *out17, double *seconds4);
 typedef struct htool_hlu_plan htool_hlu_plan;
 int htool_hlu_plan_create(const htool_cluster *root, int64_t n_leaves, const int32_t *rects5, double epsilon, int cap_min, int cap_max, double cap_factor,
-                          int64_t window_scratch_elems, int64_t window_tasks, int symmetric, htool_hlu_plan **out);
+                          int64_t window_scratch_elems, int64_t window_tasks, int symmetric, int super_rows, int solve_slots, htool_hlu_plan **out);
 int htool_hlu_plan_info(const htool_hlu_plan *plan, int64_t *out, int n_out);
 int htool_hlu_plan_program(const htool_hlu_plan *plan, int which, const void **tasks, int64_t *n_tasks, const void **buckets, int64_t *n_buckets,
                            const int64_t **seg, int64_t *n_seg, int64_t *scratch_elems, const int64_t **aux, int64_t *n_aux);

@@ -107,3 +107,25 @@ def test_symmetric_plan_is_a_hierarchical_cholesky(n, leaf, children):
     assert np.linalg.norm(x - 1) / np.sqrt(n) < eps
     other = ohlu.HostLU(plan, lambda i: H.leaf_data(int(lower[i])), eps_lu, shuffle=7)
     assert np.array_equal(lu.factor, other.factor) and np.array_equal(lu.diag, other.diag)
+
+
+@pytest.mark.parametrize("sym", [False, True])
+def test_shortened_solve_programs_give_the_same_solution(sym):
+    """The solve programs are shortened by explicit inverse factors of the small diagonal blocks and by private slots + REDUCE tasks at the
+    tree nodes above (csrc/hlu.hpp: Super, T_REDUCE): far fewer dependent levels, the same factors, the same solution to rounding."""
+    eps, eps_lu, n = 1e-3, 1e-4, 2400
+    H, cl = make_case(n, 30, eps)
+    ids = np.where(H.leaves[:, 0] >= H.leaves[:, 2])[0] if sym else np.arange(len(H.leaves))
+    leaf_data = lambda i: H.leaf_data(int(ids[i]))  # noqa: E731
+    plain = Htool.HLUPlan(cl, H.leaves[ids], eps_lu, symmetric=sym, super_rows=0, solve_slots=0)
+    short = Htool.HLUPlan(cl, H.leaves[ids], eps_lu, symmetric=sym, super_rows=256)
+    ip, is_ = dict(zip(ohlu.INFO, plain.info())), dict(zip(ohlu.INFO, short.info()))
+    assert is_["solve_levels"] < 0.5 * ip["solve_levels"] and is_["factor_tasks"] == ip["factor_tasks"]
+    a, b = ohlu.HostLU(plain, leaf_data, eps_lu), ohlu.HostLU(short, leaf_data, eps_lu)
+    nf = min(len(a.factor), len(b.factor))
+    assert np.array_equal(a.factor[:nf], b.factor[:nf])      # the factorisation itself is the same program
+    B = np.random.default_rng(8).normal(size=(n, 11))        # (more columns than a slot holds: the solve runs in chunks)
+    for trans in ("N", "T"):
+        Xa, Xb = a.solve(B, trans), b.solve(B, trans)
+        assert np.linalg.norm(Xa - Xb) / np.linalg.norm(Xa) < 1e-9
+    assert np.array_equal(b.solve(B), ohlu.HostLU(short, leaf_data, eps_lu, shuffle=4).solve(B, shuffle=6))
